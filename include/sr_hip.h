@@ -1,0 +1,152 @@
+/*
+ * sr_hip.h -- C ABI of libsr_hip.so, the MI355X (gfx950) implementation of the
+ * FRVSR / TecoGAN generator's per-frame recurrent step.
+ *
+ * The reference (javiergonzalezya13/Super-Resolution) has no native boundary:
+ * the hot path sits behind Keras `Model.predict / load_weights / save_weights`
+ * on objects built in reference FRVSR.py:27-73 and TecoGAN.py:28-85 from the
+ * blocks of reference layers.py:15-140.  Each entry point below names the
+ * reference interface it replaces.  All tensors are NHWC float32 in host or
+ * device memory exactly as Keras `predict` takes / returns them; every call
+ * returns 0 on success or a negative sr_status, with text in sr_last_error().
+ *
+ * Threading: one sr_ctx per (thread, GPU); a ctx is not thread-safe.
+ * Ownership: the caller owns every buffer it passes; no pointer is retained.
+ * There is NO CPU fallback: without a HIP device every compute call fails.
+ */
+#ifndef SR_HIP_H
+#define SR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sr_ctx sr_ctx;
+
+enum sr_status {
+    SR_OK = 0,
+    SR_ERR_ARG = -1,      /* bad argument (shape, NULL, batch > max_batch ...)   */
+    SR_ERR_SHAPE = -2,    /* h or w not a multiple of 8, scale != 4, ch != 3      */
+    SR_ERR_WEIGHTS = -3,  /* weights missing / wrong order / wrong shape          */
+    SR_ERR_HIP = -4,      /* a HIP runtime call failed (no device, OOM, ...)      */
+    SR_ERR_STATE = -5     /* call sequence error (push before begin ...)          */
+};
+
+/* arithmetic of the convolutions */
+enum sr_dtype {
+    SR_FP32 = 0,    /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 activations        */
+    SR_BF16 = 1,    /* bf16 MFMA, bf16 activations in HBM, fp32 accumulate / epilogue     */
+    SR_BF16X3 = 2   /* fp32 activations, operands split hi+lo bf16, 3 bf16 MFMAs/product  */
+};
+
+enum sr_model { SR_FRVSR = 0, SR_TECOGAN = 1 };
+
+/* activation fused into a convolution's epilogue (per-op entry points) */
+enum sr_act { SR_ACT_NONE = 0, SR_ACT_RELU = 1, SR_ACT_LRELU02 = 2, SR_ACT_TANH = 3, SR_ACT_CLIP01 = 4 };
+
+/* text of the last error on this ctx (ctx may be NULL: last error of a failed
+ * sr_create or of a per-op call on this thread).  Never NULL. */
+const char* sr_last_error(const sr_ctx* ctx);
+
+/* Number of visible HIP devices (0 when there is none); never fails. */
+int sr_device_count(void);
+
+/* Replaces FrameRecurrentVideoSR.build / TecoGAN.build (reference FRVSR.py:27-66,
+ * TecoGAN.py:28-80): fixes the LR tile shape (h, w, ch) and scale like
+ * main.py:36-46 does, allocates every activation buffer for up to max_batch
+ * tiles/clips.  h and w must be multiples of 8 (FNet's 3x pool / 3x upsample,
+ * layers.py:31-41), ch == 3, scale == 4; otherwise SR_ERR_SHAPE. */
+int sr_create(sr_ctx** out, int device, int h, int w, int ch, int scale,
+              int max_batch, int dtype, int model);
+int sr_destroy(sr_ctx* ctx);
+
+/* Run the ctx's kernels on this hipStream_t (default: a stream the ctx owns). */
+int sr_set_stream(sr_ctx* ctx, void* hip_stream);
+int sr_sync(sr_ctx* ctx);
+
+/* Replaces Model.load_weights (reference FRVSR.py:88,212,384; TecoGAN.py:158,537,709).
+ * Feed the 76 tensors of the Keras file in file order (28 under "FNet/", 48
+ * under "SRNet/"; kernel then bias per layer).  Like Keras, tensors are matched
+ * by position inside their group and checked by shape; numeric name suffixes
+ * are not interpreted.  kernel: (3,3,Cin,Cout) HWIO, transposed conv:
+ * (3,3,Cout,Cin), bias: (Cout,).  sr_commit_weights packs them into the MFMA
+ * fragment order of the ctx's dtype and uploads them. */
+int sr_load_tensor(sr_ctx* ctx, const char* keras_name, const float* host,
+                   const int64_t* shape, int rank);
+int sr_commit_weights(sr_ctx* ctx);
+/* Replaces Model.save_weights (reference FRVSR.py:193): tensor `index` (0..75)
+ * in file order.  name_out / host_out may be NULL to query name / shape only. */
+int sr_get_tensor(const sr_ctx* ctx, int index, char* name_out, int name_cap,
+                  float* host_out, int64_t* shape_out, int* rank_out);
+
+/* Replaces frvsr.predict / generator.predict (reference FRVSR.py:293,454;
+ * TecoGAN.py:618,779): [I_LR_t (B,h,w,3), I_LR_t_1 (B,h,w,3), I_est_t_1
+ * (B,4h,4w,3)] -> [I_est_t (B,4h,4w,3), I_LR_est_t_1 (B,h,w,3)].  Stateless.
+ * Host pointers; lr_warp may be NULL (the eval loops discard it). */
+int sr_step(sr_ctx* ctx, int B, const float* lr_t, const float* lr_tm1,
+            const float* est_tm1, float* est_t, float* lr_warp);
+/* Same with device pointers, asynchronous on the ctx stream (no host copies). */
+int sr_step_dev(sr_ctx* ctx, int B, const float* lr_t, const float* lr_tm1,
+                const float* est_tm1, float* est_t, float* lr_warp);
+/* Replaces hr_warping.predict (reference TecoGAN.py:83-85, call sites :329-333):
+ * same three inputs -> I_hat_est_t_1 (B,4h,4w,3), the warped previous estimate. */
+int sr_step_hr_warp(sr_ctx* ctx, int B, const float* lr_t, const float* lr_tm1,
+                    const float* est_tm1, float* hr_warp);
+
+/* The recurrent driver of reference FRVSR.py:231-234,293,309 with the state kept
+ * on the device: sr_clip_begin zeroes prev-LR and prev-estimate for B clips
+ * (tiles) advanced in lock-step; each sr_clip_push consumes frame t of all B
+ * clips (B,h,w,3) and, if est_t != NULL, copies the estimate (B,4h,4w,3) out.
+ * _dev variants take device pointers and do not synchronise. */
+int sr_clip_begin(sr_ctx* ctx, int B);
+int sr_clip_push(sr_ctx* ctx, const float* lr_t, float* est_t);
+int sr_clip_push_dev(sr_ctx* ctx, const float* lr_t, float* est_t);
+
+/* Replaces fnet.predict (reference FRVSR.py:30, layers.py:15-49):
+ * [I_LR_t, I_LR_t_1] (B,h,w,3) each -> flow (B,h,w,2). */
+int sr_fnet(sr_ctx* ctx, int B, const float* lr_t, const float* lr_tm1, float* flow);
+/* Replaces srnet.predict (reference FRVSR.py:34, layers.py:51-80):
+ * [I_LR_t (B,h,w,3), S_s (B,h,w,48)] -> (B,4h,4w,3); no TecoGAN epilogue. */
+int sr_srnet(sr_ctx* ctx, int B, const float* lr_t, const float* s_s, float* out);
+
+/* Per-kernel timing of the most recent steps: when enabled, every kernel launch
+ * of a step is bracketed by HIP events on the ctx stream.  sr_profile_read
+ * synchronises and returns, for layer i < *n, the accumulated milliseconds,
+ * launch count, algorithmic FLOPs per launch and algorithmic HBM bytes per
+ * launch, plus its name.  No reference counterpart (the reference times the whole
+ * predict with datetime.now(), FRVSR.py:292-296). */
+int sr_profile_enable(sr_ctx* ctx, int enable);
+int sr_profile_count(const sr_ctx* ctx);
+int sr_profile_read(sr_ctx* ctx, int i, char* name_out, int name_cap, double* ms_total,
+                    int64_t* launches, double* flops_per_launch, double* bytes_per_launch);
+int sr_profile_reset(sr_ctx* ctx);
+
+/* ---- single ops (host pointers, NHWC float32), used by the parity tests and by
+ * the weight-free sub-model facades.  `dtype` as enum sr_dtype. ---------------- */
+
+/* Keras Conv2D(3x3, stride 1, padding='same') + activation (+ residual add after
+ * the activation): reference layers.py:21-24,58-61.  w HWIO (3,3,Cin,Cout).
+ * res may be NULL. */
+int sr_op_conv3x3(int device, int dtype, int B, int H, int W, int Cin, int Cout,
+                  const float* x, const float* w, const float* bias, int act,
+                  const float* res, float* out);
+/* Keras Conv2DTranspose(3x3, stride 2, padding='same'): reference layers.py:71-74.
+ * w (3,3,Cout,Cin); out (B,2H,2W,Cout). */
+int sr_op_convT3x3s2(int device, int dtype, int B, int H, int W, int Cin, int Cout,
+                     const float* x, const float* w, const float* bias, int act, float* out);
+/* MaxPool2D(2x2, padding='same'): reference layers.py:31.  out (B,ceil(H/2),ceil(W/2),C). */
+int sr_op_maxpool2(int device, int B, int H, int W, int C, const float* x, float* out);
+/* UpSampling2D(size=s, interpolation='bilinear') = TF1 legacy resize: reference
+ * layers.py:37,89.  out (B,sH,sW,C). */
+int sr_op_resize_bilinear(int device, int B, int H, int W, int C, int s, const float* x, float* out);
+/* tf.contrib.image.dense_image_warp: reference layers.py:131.  flow (B,H,W,2). */
+int sr_op_warp(int device, int B, int H, int W, int C, const float* img, const float* flow, float* out);
+/* tf.space_to_depth(x, bs): reference layers.py:109.  out (B,H/bs,W/bs,bs*bs*C). */
+int sr_op_space_to_depth(int device, int B, int H, int W, int C, int bs, const float* x, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SR_HIP_H */

@@ -1,0 +1,433 @@
+// Bandwidth-bound kernels of the generator step (gfx950): everything of
+// reference FRVSR.py:58-63 / TecoGAN.py:74-76 that is not a convolution.
+//   pre_srnet    bilinear x4 of the flow (layers.py:89) + dense_image_warp of the
+//                previous HR estimate (layers.py:131) + space_to_depth (layers.py:109)
+//                + concat with the LR frame (layers.py:66), one pass, NHWC out
+//   fnet_input   concat [LR_t, LR_t-1] (layers.py:29), zero padded to 16 channels
+//   maxpool2     MaxPool2D 2x2 SAME (layers.py:31,33,35)
+//   resize2x     TF1-legacy bilinear x2 (layers.py:37,39,41)
+//   warp3        LR warp, second model output (FRVSR.py:59)
+//   teco_epilogue tanh(SRNet + bilinear x4 (LR_t)) (TecoGAN.py:74-76)
+// Activations are [B,H,W,C] with C a multiple of 16, float or bf16 (template T).
+#include "kernels.h"
+
+namespace sr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- 16-byte activation vectors: 4 floats or 8 bf16, processed as floats ----
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    f32x4 v;
+    __device__ float get(int i) const { return v[i]; }
+    __device__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec<__bf16> {
+    static constexpr int N = 8;
+    bf16x8 v;
+    __device__ float get(int i) const { return (float)v[i]; }
+    __device__ void set(int i, float x) { v[i] = (__bf16)x; }
+};
+
+static inline int blocks_for(long n, int bs) { return (int)((n + bs - 1) / bs); }
+
+// legacy TF1 bilinear: top = tl + (tr-tl)*tx ; bot likewise ; out = top + (bot-top)*ty
+__device__ __forceinline__ float lerp2(float tl, float tr, float bl, float br, float tx, float ty) {
+    const float top = tl + (tr - tl) * tx;
+    const float bot = bl + (br - bl) * tx;
+    return top + (bot - top) * ty;
+}
+
+// ------------------------------------------------------------------ fnet_input
+template <typename T>
+__global__ void fnet_input_kernel(const float* __restrict__ a, const float* __restrict__ b, T* __restrict__ out, long npix) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        v[c] = a[p * 3 + c];
+        v[3 + c] = b[p * 3 + c];
+    }
+#pragma unroll
+    for (int c = 6; c < 16; ++c) v[c] = 0.f;
+    constexpr int N = Vec<T>::N;
+    Vec<T>* o = reinterpret_cast<Vec<T>*>(out + p * 16);
+#pragma unroll
+    for (int q = 0; q < 16 / N; ++q) {
+        Vec<T> w;
+#pragma unroll
+        for (int i = 0; i < N; ++i) w.set(i, v[q * N + i]);
+        o[q] = w;
+    }
+}
+
+hipError_t launch_fnet_input(const float* lr_t, const float* lr_tm1, void* out, int act_bf16,
+                             int B, int H, int W, hipStream_t s) {
+    const long npix = (long)B * H * W;
+    if (act_bf16)
+        hipLaunchKernelGGL(fnet_input_kernel<__bf16>, dim3(blocks_for(npix, 256)), dim3(256), 0, s, lr_t, lr_tm1, (__bf16*)out, npix);
+    else
+        hipLaunchKernelGGL(fnet_input_kernel<float>, dim3(blocks_for(npix, 256)), dim3(256), 0, s, lr_t, lr_tm1, (float*)out, npix);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ srnet_input (stand-alone SRNet.predict)
+template <typename T>
+__global__ void srnet_input_kernel(const float* __restrict__ lr, const float* __restrict__ ss, T* __restrict__ out, long npix) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long p = idx >> 6;
+    const int c = idx & 63;
+    if (p >= npix) return;
+    float v = 0.f;
+    if (c < 3) v = lr[p * 3 + c];
+    else if (c < 51) v = ss[p * 48 + c - 3];
+    out[p * 64 + c] = (T)v;
+}
+
+hipError_t launch_srnet_input(const float* lr_t, const float* s_s, void* out, int act_bf16,
+                              int B, int H, int W, hipStream_t s) {
+    const long npix = (long)B * H * W;
+    if (act_bf16)
+        hipLaunchKernelGGL(srnet_input_kernel<__bf16>, dim3(blocks_for(npix * 64, 256)), dim3(256), 0, s, lr_t, s_s, (__bf16*)out, npix);
+    else
+        hipLaunchKernelGGL(srnet_input_kernel<float>, dim3(blocks_for(npix * 64, 256)), dim3(256), 0, s, lr_t, s_s, (float*)out, npix);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ maxpool2 (vectorised over channels)
+template <typename T>
+__global__ void maxpool2_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C) {
+    constexpr int N = Vec<T>::N;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, CV = C / N;
+    const long total = (long)B * Ho * Wo * CV;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = idx % CV;
+    long p = idx / CV;
+    const int ox = p % Wo;
+    p /= Wo;
+    const int oy = p % Ho;
+    const int b = p / Ho;
+    const int y0 = 2 * oy, x0 = 2 * ox;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);   // SAME: the -inf pad never wins
+    const Vec<T>* base = reinterpret_cast<const Vec<T>*>(in + (size_t)b * H * W * C) + cv;
+    const Vec<T> a = base[((size_t)y0 * W + x0) * CV], bq = base[((size_t)y0 * W + x1) * CV];
+    const Vec<T> c = base[((size_t)y1 * W + x0) * CV], d = base[((size_t)y1 * W + x1) * CV];
+    Vec<T> o;
+#pragma unroll
+    for (int i = 0; i < N; ++i) o.set(i, fmaxf(fmaxf(a.get(i), bq.get(i)), fmaxf(c.get(i), d.get(i))));
+    reinterpret_cast<Vec<T>*>(out)[idx] = o;
+}
+
+hipError_t launch_maxpool2(const void* in, void* out, int act_bf16, int B, int H, int W, int C, hipStream_t s) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    if (act_bf16) {
+        const long total = (long)B * Ho * Wo * (C / 8);
+        hipLaunchKernelGGL(maxpool2_kernel<__bf16>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const __bf16*)in, (__bf16*)out, B, H, W, C);
+    } else {
+        const long total = (long)B * Ho * Wo * (C / 4);
+        hipLaunchKernelGGL(maxpool2_kernel<float>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const float*)in, (float*)out, B, H, W, C);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ resize2x (legacy bilinear, vectorised)
+template <typename T>
+__global__ void resize2x_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C) {
+    constexpr int N = Vec<T>::N;
+    const int Ho = 2 * H, Wo = 2 * W, CV = C / N;
+    const long total = (long)B * Ho * Wo * CV;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = idx % CV;
+    long p = idx / CV;
+    const int ox = p % Wo;
+    p /= Wo;
+    const int oy = p % Ho;
+    const int b = p / Ho;
+    const int y0 = oy >> 1, x0 = ox >> 1;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ty = (oy & 1) * 0.5f, tx = (ox & 1) * 0.5f;
+    const Vec<T>* base = reinterpret_cast<const Vec<T>*>(in + (size_t)b * H * W * C) + cv;
+    const Vec<T> tl = base[((size_t)y0 * W + x0) * CV], tr = base[((size_t)y0 * W + x1) * CV];
+    const Vec<T> bl = base[((size_t)y1 * W + x0) * CV], br = base[((size_t)y1 * W + x1) * CV];
+    Vec<T> o;
+#pragma unroll
+    for (int i = 0; i < N; ++i) o.set(i, lerp2(tl.get(i), tr.get(i), bl.get(i), br.get(i), tx, ty));
+    reinterpret_cast<Vec<T>*>(out)[idx] = o;
+}
+
+hipError_t launch_resize2x(const void* in, void* out, int act_bf16, int B, int H, int W, int C, hipStream_t s) {
+    if (act_bf16) {
+        const long total = (long)B * 4 * H * W * (C / 8);
+        hipLaunchKernelGGL(resize2x_kernel<__bf16>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const __bf16*)in, (__bf16*)out, B, H, W, C);
+    } else {
+        const long total = (long)B * 4 * H * W * (C / 4);
+        hipLaunchKernelGGL(resize2x_kernel<float>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const float*)in, (float*)out, B, H, W, C);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ dense_image_warp helpers
+struct WarpCoord {
+    int f;
+    float a;
+};
+// floor clamped to [0, n-2]; alpha from the CLAMPED floor, clamped to [0,1]  
+__device__ __forceinline__ WarpCoord warp_coord(float q, int n) {
+    float f = floorf(q);
+    f = fminf(fmaxf(f, 0.f), (float)(n - 2));
+    WarpCoord w;
+    w.f = (int)f;
+    w.a = fminf(fmaxf(q - f, 0.f), 1.f);
+    return w;
+}
+__device__ __forceinline__ float warp_interp(float tl, float tr, float bl, float br, float ax, float ay) {
+    const float top = ax * (tr - tl) + tl;
+    const float bot = ax * (br - bl) + bl;
+    return ay * (bot - top) + top;
+}
+
+// ------------------------------------------------------------------ pre_srnet (the fused hot-path gather)
+// One workgroup = 64 consecutive LR pixels x 4 sub-rows (dy).  Thread (lp, dy) upsamples the
+// flow for its 4 HR pixels, gathers/warps 4 x 3 values of the previous estimate and drops them
+// at channels 3 + dy*12 .. of its pixel's 64-channel row in LDS; rows go out as 16-B vectors.
+template <typename T, bool WRITE_HR>
+__global__ __launch_bounds__(256) void pre_srnet_kernel(const float* __restrict__ flow, const float* __restrict__ est,
+                                                        const float* __restrict__ lr, T* __restrict__ out,
+                                                        float* __restrict__ hr_out, int B, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float rows[64][64 + 4];
+    const long npix = (long)B * H * W;
+    const int lp = threadIdx.x >> 2, dy = threadIdx.x & 3;
+    const long p = (long)blockIdx.x * 64 + lp;
+    if (p < npix) {
+        const int x = p % W;
+        long q = p / W;
+        const int y = q % H;
+        const int b = q / H;
+        const int x1 = min(x + 1, W - 1), y1 = min(y + 1, H - 1);
+        const float* fb = flow + (size_t)b * H * W * 2;
+        const float2 ftl = *reinterpret_cast<const float2*>(fb + ((size_t)y * W + x) * 2);
+        const float2 ftr = *reinterpret_cast<const float2*>(fb + ((size_t)y * W + x1) * 2);
+        const float2 fbl = *reinterpret_cast<const float2*>(fb + ((size_t)y1 * W + x) * 2);
+        const float2 fbr = *reinterpret_cast<const float2*>(fb + ((size_t)y1 * W + x1) * 2);
+        const int HH = 4 * H, WW = 4 * W;
+        const float* eb = est + (size_t)b * HH * WW * 3;
+        const float ty = dy * 0.25f;
+        const int Y = 4 * y + dy;
+        float vals[12];
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const float tx = dx * 0.25f;
+            const float fy = lerp2(ftl.x, ftr.x, fbl.x, fbr.x, tx, ty);   // F_HR is NOT rescaled (FRVSR.py:60)
+            const float fx = lerp2(ftl.y, ftr.y, fbl.y, fbr.y, tx, ty);
+            const int X = 4 * x + dx;
+            const WarpCoord cy = warp_coord((float)Y - fy, HH);
+            const WarpCoord cx = warp_coord((float)X - fx, WW);
+            const float* r0 = eb + ((size_t)cy.f * WW + cx.f) * 3;
+            const float* r1 = r0 + (size_t)WW * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                vals[dx * 3 + c] = warp_interp(r0[c], r0[3 + c], r1[c], r1[3 + c], cx.a, cy.a);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) rows[lp][3 + dy * 12 + i] = vals[i];
+        if (dy == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rows[lp][c] = lr[p * 3 + c];
+        } else if (dy == 1) {
+#pragma unroll
+            for (int c = 51; c < 64; ++c) rows[lp][c] = 0.f;
+        }
+        if constexpr (WRITE_HR) {
+            f32x4* o = reinterpret_cast<f32x4*>(hr_out + (((size_t)b * HH + Y) * WW + 4 * x) * 3);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                f32x4 w = {vals[4 * i], vals[4 * i + 1], vals[4 * i + 2], vals[4 * i + 3]};
+                o[i] = w;
+            }
+        }
+    }
+    __syncthreads();
+    // 64 rows x 64 channels -> global, 16 B per thread per pass, fully coalesced
+    constexpr int N = Vec<T>::N;
+    constexpr int VPR = 64 / N;               // vectors per row
+    for (int v = threadIdx.x; v < 64 * VPR; v += 256) {
+        const int row = v / VPR, part = v % VPR;
+        const long pp = (long)blockIdx.x * 64 + row;
+        if (pp < npix) {
+            Vec<T> w;
+#pragma unroll
+            for (int i = 0; i < N; ++i) w.set(i, rows[row][part * N + i]);
+            reinterpret_cast<Vec<T>*>(out + pp * 64)[part] = w;
+        }
+    }
+}
+
+hipError_t launch_pre_srnet(const float* flow, const float* est_prev, const float* lr_t, void* out,
+                            float* hr_warp_out, int act_bf16, int B, int H, int W, hipStream_t s) {
+    const long npix = (long)B * H * W;
+    const dim3 grid(blocks_for(npix, 64)), block(256);
+    if (act_bf16) {
+        if (hr_warp_out) hipLaunchKernelGGL((pre_srnet_kernel<__bf16, true>), grid, block, 0, s, flow, est_prev, lr_t, (__bf16*)out, hr_warp_out, B, H, W);
+        else hipLaunchKernelGGL((pre_srnet_kernel<__bf16, false>), grid, block, 0, s, flow, est_prev, lr_t, (__bf16*)out, hr_warp_out, B, H, W);
+    } else {
+        if (hr_warp_out) hipLaunchKernelGGL((pre_srnet_kernel<float, true>), grid, block, 0, s, flow, est_prev, lr_t, (float*)out, hr_warp_out, B, H, W);
+        else hipLaunchKernelGGL((pre_srnet_kernel<float, false>), grid, block, 0, s, flow, est_prev, lr_t, (float*)out, hr_warp_out, B, H, W);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ generic dense_image_warp (any C) and the 3-channel LR warp
+__global__ void warp_generic_kernel(const float* __restrict__ img, const float* __restrict__ flow, float* __restrict__ out,
+                                    int B, int H, int W, int C) {
+    const long npix = (long)B * H * W;
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const int x = p % W;
+    long q = p / W;
+    const int y = q % H;
+    const int b = q / H;
+    const float2 f = *reinterpret_cast<const float2*>(flow + p * 2);
+    const WarpCoord cy = warp_coord((float)y - f.x, H);
+    const WarpCoord cx = warp_coord((float)x - f.y, W);
+    const float* r0 = img + (((size_t)b * H + cy.f) * W + cx.f) * C;
+    const float* r1 = r0 + (size_t)W * C;
+    for (int c = 0; c < C; ++c)
+        out[p * C + c] = warp_interp(r0[c], r0[C + c], r1[c], r1[C + c], cx.a, cy.a);
+}
+
+hipError_t launch_warp_generic(const float* img, const float* flow, float* out, int B, int H, int W, int C, hipStream_t s) {
+    const long npix = (long)B * H * W;
+    hipLaunchKernelGGL(warp_generic_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, s, img, flow, out, B, H, W, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_warp3(const float* img, const float* flow, float* out, int B, int H, int W, hipStream_t s) {
+    return launch_warp_generic(img, flow, out, B, H, W, 3, s);
+}
+
+// ------------------------------------------------------------------ TecoGAN epilogue: est = tanh(est + up4(lr))
+__global__ void teco_epilogue_kernel(float* __restrict__ est, const float* __restrict__ lr, int B, int H, int W) {
+    const int HH = 4 * H, WW = 4 * W;
+    const long npix = (long)B * HH * WW;
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const int X = p % WW;
+    long q = p / WW;
+    const int Y = q % HH;
+    const int b = q / HH;
+    const int y0 = Y >> 2, x0 = X >> 2;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ty = (Y & 3) * 0.25f, tx = (X & 3) * 0.25f;
+    const float* lb = lr + (size_t)b * H * W * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float up = lerp2(lb[((size_t)y0 * W + x0) * 3 + c], lb[((size_t)y0 * W + x1) * 3 + c],
+                               lb[((size_t)y1 * W + x0) * 3 + c], lb[((size_t)y1 * W + x1) * 3 + c], tx, ty);
+        est[p * 3 + c] = tanhf(est[p * 3 + c] + up);
+    }
+}
+
+hipError_t launch_teco_epilogue(float* est, const float* lr_t, int B, int H, int W, hipStream_t s) {
+    const long npix = (long)B * 16 * H * W;
+    hipLaunchKernelGGL(teco_epilogue_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, s, est, lr_t, B, H, W);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ generic single ops (per-op entry points)
+template <typename T>
+__global__ void pad_channels_kernel(const float* __restrict__ in, T* __restrict__ out, long npix, int C, int Cp) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * Cp) return;
+    const long p = idx / Cp;
+    const int c = idx % Cp;
+    out[idx] = (T)(c < C ? in[p * C + c] : 0.f);
+}
+
+hipError_t launch_pad_channels(const float* in, void* out, int out_bf16, long npix, int C, int Cp, hipStream_t s) {
+    const long total = npix * Cp;
+    if (out_bf16) hipLaunchKernelGGL(pad_channels_kernel<__bf16>, dim3(blocks_for(total, 256)), dim3(256), 0, s, in, (__bf16*)out, npix, C, Cp);
+    else hipLaunchKernelGGL(pad_channels_kernel<float>, dim3(blocks_for(total, 256)), dim3(256), 0, s, in, (float*)out, npix, C, Cp);
+    return hipGetLastError();
+}
+
+__global__ void maxpool2_generic_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long total = (long)B * Ho * Wo * C;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % C;
+    long p = idx / C;
+    const int ox = p % Wo;
+    p /= Wo;
+    const int oy = p % Ho;
+    const int b = p / Ho;
+    float m = -INFINITY;
+    for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+            const int y = 2 * oy + dy, x = 2 * ox + dx;
+            if (y < H && x < W) m = fmaxf(m, in[(((size_t)b * H + y) * W + x) * C + c]);
+        }
+    out[idx] = m;
+}
+
+hipError_t launch_maxpool2_generic(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
+    const long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * C;
+    hipLaunchKernelGGL(maxpool2_generic_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, in, out, B, H, W, C);
+    return hipGetLastError();
+}
+
+__global__ void resize_generic_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C, int sc) {
+    const int Ho = sc * H, Wo = sc * W;
+    const long total = (long)B * Ho * Wo * C;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % C;
+    long p = idx / C;
+    const int ox = p % Wo;
+    p /= Wo;
+    const int oy = p % Ho;
+    const int b = p / Ho;
+    const float sy = (float)oy / (float)sc, sx = (float)ox / (float)sc;   // src = dst / s
+    const int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ty = sy - (float)y0, tx = sx - (float)x0;
+    const float* base = in + (size_t)b * H * W * C + c;
+    out[idx] = lerp2(base[((size_t)y0 * W + x0) * C], base[((size_t)y0 * W + x1) * C],
+                     base[((size_t)y1 * W + x0) * C], base[((size_t)y1 * W + x1) * C], tx, ty);
+}
+
+hipError_t launch_resize_generic(const float* in, float* out, int B, int H, int W, int C, int sc, hipStream_t s) {
+    const long total = (long)B * sc * H * sc * W * C;
+    hipLaunchKernelGGL(resize_generic_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, in, out, B, H, W, C, sc);
+    return hipGetLastError();
+}
+
+__global__ void s2d_generic_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C, int bs) {
+    // out[b,h,w,(dy*bs+dx)*C + c] = in[b, bs*h+dy, bs*w+dx, c]
+    const long total = (long)B * H * W * C;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % C;
+    long p = idx / C;
+    const int x = p % W;
+    p /= W;
+    const int y = p % H;
+    const int b = p / H;
+    const int Ho = H / bs, Wo = W / bs;
+    const int oy = y / bs, dy = y % bs, ox = x / bs, dx = x % bs;
+    out[(((size_t)b * Ho + oy) * Wo + ox) * (size_t)(bs * bs * C) + (dy * bs + dx) * C + c] = in[idx];
+}
+
+hipError_t launch_s2d_generic(const float* in, float* out, int B, int H, int W, int C, int bs, hipStream_t s) {
+    const long total = (long)B * H * W * C;
+    hipLaunchKernelGGL(s2d_generic_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, in, out, B, H, W, C, bs);
+    return hipGetLastError();
+}
+
+}  // namespace sr

@@ -1,0 +1,64 @@
+// Shared declarations between the HIP kernels and the C-ABI host layer.
+// gfx950 only; see DESIGN.md for the data layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sr {
+
+enum Prec { P_FP32 = 0, P_BF16 = 1, P_BF16X3 = 2 };
+enum Act { A_NONE = 0, A_RELU = 1, A_LRELU = 2, A_TANH = 3, A_CLIP01 = 4 };
+enum ConvMode { M_CONV = 0, M_CONVT = 1 };
+
+// Geometry of the conv kernels: a workgroup (256 threads = 4 waves) computes a
+// TH x 32 pixel tile of NT*32 output channels; the (TH+2) x 34 halo tile of one
+// input-channel chunk is staged in LDS, pixel-major, 16 B of padding per pixel.
+constexpr int TW = 32;
+constexpr int HALO_W = TW + 2;
+
+struct ConvArgs {
+    const void* in;        // [B,H,W,cin_p] activations (float or bf16)
+    const void* wpack;     // packed weights, MFMA fragment order (see pack_weights)
+    const float* bias;     // [ncb * NT*32] fp32, zero padded
+    void* out;             // [B,Ho,Wo,out_cs]
+    const void* res;       // residual added after the activation, or nullptr
+    int B, H, W;           // input spatial dims (output = same, or 2x for M_CONVT)
+    int cin_p;             // input pixel stride in elements (multiple of 16)
+    int out_cs;            // output pixel stride in elements
+    int res_cs;            // residual pixel stride in elements
+    int cout_store;        // number of output channels actually stored
+    int out_f32;           // 1: out/res are float, 0: bf16
+    int act;
+    int tiles_x, tiles_y;
+    int nchunk;            // number of input-channel chunks
+    int wstride_cb;        // 16-byte vectors of wpack per output-channel block
+};
+
+// steps per chunk / chunk geometry, shared by the packer and the kernel
+__host__ __device__ constexpr int prec_ks(int prec) { return prec == P_FP32 ? 8 : 16; }      // channels per k-step
+__host__ __device__ constexpr int prec_maxsteps(int prec) { return prec == P_BF16X3 ? 2 : 4; }
+
+// host-side launchers (conv_mfma.hip)
+hipError_t launch_conv(int prec, int mode, int nt, int steps, const ConvArgs& a, int ncb, hipStream_t s);
+size_t conv_lds_bytes(int prec, int mode, int steps);
+
+// element-wise / gather kernels (fused_ops.hip).  act_bf16: activations are bf16.
+hipError_t launch_fnet_input(const float* lr_t, const float* lr_tm1, void* out, int act_bf16,
+                             int B, int H, int W, hipStream_t s);
+hipError_t launch_maxpool2(const void* in, void* out, int act_bf16, int B, int H, int W, int C, hipStream_t s);
+hipError_t launch_resize2x(const void* in, void* out, int act_bf16, int B, int H, int W, int C, hipStream_t s);
+hipError_t launch_pre_srnet(const float* flow, const float* est_prev, const float* lr_t, void* out,
+                            float* hr_warp_out, int act_bf16, int B, int H, int W, hipStream_t s);
+hipError_t launch_srnet_input(const float* lr_t, const float* s_s, void* out, int act_bf16,
+                              int B, int H, int W, hipStream_t s);
+hipError_t launch_warp3(const float* img, const float* flow, float* out, int B, int H, int W, hipStream_t s);
+hipError_t launch_teco_epilogue(float* est, const float* lr_t, int B, int H, int W, hipStream_t s);
+
+// generic fp32 single ops for the per-op C-ABI entry points
+hipError_t launch_pad_channels(const float* in, void* out, int out_bf16, long npix, int C, int Cp, hipStream_t s);
+hipError_t launch_maxpool2_generic(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
+hipError_t launch_resize_generic(const float* in, float* out, int B, int H, int W, int C, int sc, hipStream_t s);
+hipError_t launch_warp_generic(const float* img, const float* flow, float* out, int B, int H, int W, int C, hipStream_t s);
+hipError_t launch_s2d_generic(const float* in, float* out, int B, int H, int W, int C, int bs, hipStream_t s);
+
+}  // namespace sr

@@ -1,0 +1,876 @@
+// C-ABI host layer of libsr_hip.so (declared in include/sr_hip.h).
+// Owns device memory, packs Keras-layout weights into MFMA fragment order and
+// runs the generator step of reference FRVSR.py:58-66 / TecoGAN.py:68-79 as a
+// fixed sequence of HIP kernel launches on one stream.  No CPU fallback.
+#include "../../include/sr_hip.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace sr;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct HostTensor {
+    std::string name;
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct ConvLayer {
+    int mode = M_CONV;
+    int cin = 0, cout = 0, cin_p = 0;
+    int nt = 1, ncb = 1, steps = 1, nchunk = 1, wstride_cb = 0;
+    void* d_w = nullptr;
+    float* d_bias = nullptr;
+    double wbytes = 0;
+};
+
+struct ProfEntry {
+    std::string name;
+    double ms = 0, flops = 0, bytes = 0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+uint16_t f2bf(float f) {   // round to nearest even
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+float bf2f(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+}  // namespace
+
+struct sr_ctx {
+    int device = 0, h = 0, w = 0, max_batch = 0, prec = P_FP32, model = SR_FRVSR;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // weights
+    std::vector<HostTensor> tensors;      // file order
+    int n_fnet = 0, n_srnet = 0;
+    bool committed = false;
+    ConvLayer fnet[14], srnet[24];
+    // activations
+    std::map<std::string, void*> buf;
+    float *d_lr_t = nullptr, *d_lr_tm1 = nullptr, *d_est[2] = {nullptr, nullptr}, *d_flow = nullptr;
+    float *d_lr_warp = nullptr, *d_hr_warp = nullptr, *d_ss = nullptr;
+    // recurrent state
+    bool clip_active = false;
+    int clip_B = 0, cur = 0;
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfEntry> prof;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+int fail(sr_ctx* c, int code, const char* fmt, ...) {
+    char tmp[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tmp, sizeof tmp, fmt, ap);
+    va_end(ap);
+    g_err = tmp;
+    if (c) c->err = tmp;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return fail(c, SR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------- weight packing
+// Order inside one output-channel block: [chunk][tap][step][n block][hi,lo][lane] x 16 B,
+// lane (j = lane & 31, hh = lane >> 5) holding input channels
+//   chunk*CKC + step*KS + (KS/2)*hh + e   (e < KS/2)   of output channel cb*NT*32 + n*32 + j,
+// i.e. exactly the B fragment of v_mfma_f32_32x32x2_f32 (4 successive k-pairs per vector)
+// or v_mfma_f32_32x32x16_bf16 that conv3x3_kernel consumes.
+void plan_layer(ConvLayer& L, int prec, int mode, int cin, int cout) {
+    L.mode = mode;
+    L.cin = cin;
+    L.cout = cout;
+    L.cin_p = round_up(cin, 16);
+    const int ks = prec_ks(prec);
+    const int total_steps = L.cin_p / ks;
+    int steps = prec_maxsteps(prec);
+    while (total_steps % steps) steps >>= 1;
+    L.steps = steps;
+    L.nchunk = total_steps / steps;
+    L.nt = (mode == M_CONVT || cout > 32) ? 2 : 1;
+    L.ncb = (cout + 32 * L.nt - 1) / (32 * L.nt);
+    const int bv = prec == P_BF16X3 ? 2 : 1;
+    L.wstride_cb = L.nchunk * 9 * L.steps * L.nt * bv * 64;
+}
+
+std::vector<uint8_t> pack_weights(const ConvLayer& L, int prec, const float* w) {
+    const int ks = prec_ks(prec), half = ks / 2;
+    const int bv = prec == P_BF16X3 ? 2 : 1;
+    const int ckc = L.steps * ks;
+    std::vector<uint8_t> out((size_t)L.ncb * L.wstride_cb * 16, 0);
+    auto W = [&](int ky, int kx, int ci, int co) -> float {
+        if (ci >= L.cin || co >= L.cout) return 0.f;
+        if (L.mode == M_CONV) return w[((size_t)(ky * 3 + kx) * L.cin + ci) * L.cout + co];
+        return w[((size_t)(ky * 3 + kx) * L.cout + co) * L.cin + ci];   // Conv2DTranspose: (kh,kw,out,in)
+    };
+    for (int cb = 0; cb < L.ncb; ++cb)
+        for (int c = 0; c < L.nchunk; ++c)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int s = 0; s < L.steps; ++s)
+                    for (int n = 0; n < L.nt; ++n)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int j = lane & 31, hh = lane >> 5;
+                            const int co = (cb * L.nt + n) * 32 + j;
+                            const size_t vbase = (size_t)cb * L.wstride_cb +
+                                                 ((size_t)((c * 9 + tap) * L.steps + s) * L.nt + n) * bv * 64;
+                            for (int e = 0; e < half; ++e) {
+                                const int ci = c * ckc + s * ks + half * hh + e;
+                                const float v = W(tap / 3, tap % 3, ci, co);
+                                if (prec == P_FP32) {
+                                    memcpy(&out[(vbase + lane) * 16 + e * 4], &v, 4);
+                                } else {
+                                    const uint16_t hi = f2bf(v);
+                                    memcpy(&out[(vbase + lane) * 16 + e * 2], &hi, 2);
+                                    if (prec == P_BF16X3) {
+                                        const uint16_t lo = f2bf(v - bf2f(hi));
+                                        memcpy(&out[(vbase + 64 + lane) * 16 + e * 2], &lo, 2);
+                                    }
+                                }
+                            }
+                        }
+    return out;
+}
+
+int upload_layer(sr_ctx* c, ConvLayer& L, int prec, const float* w, const float* bias) {
+    std::vector<uint8_t> packed = pack_weights(L, prec, w);
+    std::vector<float> b((size_t)L.ncb * L.nt * 32, 0.f);
+    for (int i = 0; i < L.cout; ++i) b[i] = bias[i];
+    if (L.d_w) (void)hipFree(L.d_w);
+    if (L.d_bias) (void)hipFree(L.d_bias);
+    L.d_w = nullptr;
+    L.d_bias = nullptr;
+    HIPCHK(c, hipMalloc(&L.d_w, packed.size()));
+    HIPCHK(c, hipMalloc((void**)&L.d_bias, b.size() * 4));
+    HIPCHK(c, hipMemcpy(L.d_w, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(L.d_bias, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+    L.wbytes = (double)packed.size();
+    return SR_OK;
+}
+
+void free_layer(ConvLayer& L) {
+    if (L.d_w) (void)hipFree(L.d_w);
+    if (L.d_bias) (void)hipFree(L.d_bias);
+    L.d_w = nullptr;
+    L.d_bias = nullptr;
+}
+
+// ---------------------------------------------------------------- profiling helpers
+ProfEntry* prof_entry(sr_ctx* c, const char* name) {
+    for (auto& e : c->prof)
+        if (e.name == name) return &e;
+    c->prof.push_back(ProfEntry());
+    c->prof.back().name = name;
+    return &c->prof.back();
+}
+
+hipEvent_t get_event(sr_ctx* c) {
+    if (!c->ev_pool.empty()) {
+        hipEvent_t e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    sr_ctx* c;
+    size_t idx = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(sr_ctx* c_, const char* name, double flops, double bytes) : c(c_) {
+        if (!c->prof_on) return;
+        ProfEntry* p = prof_entry(c, name);
+        idx = p - c->prof.data();
+        p->flops = flops;
+        p->bytes = bytes;
+        p->launches++;
+        e0 = get_event(c);
+        e1 = get_event(c);
+        (void)hipEventRecord(e0, c->stream);
+    }
+    ~ProfScope() {
+        if (!e0) return;
+        (void)hipEventRecord(e1, c->stream);
+        c->prof[idx].pending.emplace_back(e0, e1);
+    }
+};
+
+void prof_resolve(sr_ctx* c) {
+    for (auto& p : c->prof) {
+        for (auto& ev : p.pending) {
+            float ms = 0.f;
+            (void)hipEventSynchronize(ev.second);
+            (void)hipEventElapsedTime(&ms, ev.first, ev.second);
+            p.ms += ms;
+            c->ev_pool.push_back(ev.first);
+            c->ev_pool.push_back(ev.second);
+        }
+        p.pending.clear();
+    }
+}
+
+// ---------------------------------------------------------------- layer launch
+struct ConvIO {
+    const void* in;
+    int H, W;              // input spatial size
+    void* out;
+    int out_cs, cout_store, out_f32;
+    const void* res;
+    int res_cs;
+    int act;
+};
+
+int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, const ConvIO& io, const char* name) {
+    ConvArgs a;
+    a.in = io.in;
+    a.wpack = L.d_w;
+    a.bias = L.d_bias;
+    a.out = io.out;
+    a.res = io.res;
+    a.B = B;
+    a.H = io.H;
+    a.W = io.W;
+    a.cin_p = L.cin_p;
+    a.out_cs = io.out_cs;
+    a.res_cs = io.res_cs;
+    a.cout_store = io.cout_store;
+    a.out_f32 = io.out_f32;
+    a.act = io.act;
+    const int th = L.mode == M_CONV ? 8 : 4;
+    a.tiles_x = (io.W + TW - 1) / TW;
+    a.tiles_y = (io.H + th - 1) / th;
+    a.nchunk = L.nchunk;
+    a.wstride_cb = L.wstride_cb;
+    if (io.cout_store > L.ncb * L.nt * 32) return fail(c, SR_ERR_ARG, "%s: cout_store out of range", name);
+    const double px = (double)B * io.H * io.W;
+    const double esz_in = prec == P_BF16 ? 2 : 4, esz_out = io.out_f32 ? 4 : 2;
+    const double opx = L.mode == M_CONV ? px : 4 * px;
+    const double flops = px * 9.0 * L.cin * L.cout * 2.0;
+    const double bytes = px * L.cin * esz_in + opx * io.cout_store * esz_out * (io.res ? 2 : 1) + L.wbytes;
+    hipError_t e;
+    if (c) {
+        ProfScope ps(c, name, flops, bytes);
+        e = launch_conv(prec, L.mode, L.nt, L.steps, a, L.ncb, st);
+    } else {
+        e = launch_conv(prec, L.mode, L.nt, L.steps, a, L.ncb, st);
+    }
+    if (e != hipSuccess) return fail(c, SR_ERR_HIP, "launch %s: %s", name, hipGetErrorString(e));
+    return SR_OK;
+}
+
+#define LAUNCHCHK(c, name, call)                                                               \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) return fail(c, SR_ERR_HIP, "launch %s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+int alloc_buf(sr_ctx* c, const char* name, size_t bytes) {
+    void* p = nullptr;
+    HIPCHK(c, hipMalloc(&p, bytes));
+    c->buf[name] = p;
+    return SR_OK;
+}
+
+// expected (cin, cout, mode) of every weighted layer, reference layers.py:30-44,67-75
+const int FNET_SPEC[14][2] = {{6, 32}, {32, 32}, {32, 64}, {64, 64}, {64, 128}, {128, 128}, {128, 256},
+                              {256, 256}, {256, 128}, {128, 128}, {128, 64}, {64, 64}, {64, 32}, {32, 2}};
+
+void srnet_spec(int i, int& cin, int& cout, int& mode) {
+    mode = (i == 21 || i == 22) ? M_CONVT : M_CONV;
+    cin = i == 0 ? 51 : 64;
+    cout = i == 23 ? 3 : 64;
+}
+
+int check_ready(sr_ctx* c, int B) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    if (!c->committed) return fail(c, SR_ERR_WEIGHTS, "weights not committed (sr_load_tensor x76 + sr_commit_weights)");
+    if (B < 1 || B > c->max_batch) return fail(c, SR_ERR_ARG, "batch %d outside [1, max_batch=%d]", B, c->max_batch);
+    HIPCHK(c, hipSetDevice(c->device));
+    return SR_OK;
+}
+
+// FNet: reference layers.py:27-45
+int run_fnet(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, float* d_flow) {
+    const int bf = c->prec == P_BF16, P = c->prec;
+    const int af = bf ? 0 : 1;   // activations are float?
+    hipStream_t st = c->stream;
+    const int H = c->h, W = c->w;
+    auto b = [&](const char* n) { return c->buf[n]; };
+    {
+        ProfScope ps(c, "fnet.input", 0, (double)B * H * W * (24 + 16 * (bf ? 2 : 4)));
+        LAUNCHCHK(c, "fnet.input", launch_fnet_input(d_lr_t, d_lr_tm1, b("x0"), bf, B, H, W, st));
+    }
+    struct Lvl { int H, W; } lv[4] = {{H, W}, {H / 2, W / 2}, {H / 4, W / 4}, {H / 8, W / 8}};
+    const char* A[4] = {"a0", "a1", "a2", "a3"};
+    const char* Bb[4] = {"b0", "b1", "b2", "b3"};
+    const char* Pn[4] = {nullptr, "p1", "p2", "p3"};
+    const char* Un[3] = {"u0", "u1", "u2"};
+    const int ch[4] = {32, 64, 128, 256};
+    char nm[32];
+    int k = 0;
+    const void* x = b("x0");
+    // encoder
+    for (int l = 0; l < 4; ++l) {
+        snprintf(nm, sizeof nm, "fnet.conv%d", k + 1);
+        int rc = run_conv(c, P, st, c->fnet[k++], B, {x, lv[l].H, lv[l].W, b(A[l]), ch[l], ch[l], af, nullptr, 0, A_LRELU}, nm);
+        if (rc) return rc;
+        snprintf(nm, sizeof nm, "fnet.conv%d", k + 1);
+        rc = run_conv(c, P, st, c->fnet[k++], B, {b(A[l]), lv[l].H, lv[l].W, b(Bb[l]), ch[l], ch[l], af, nullptr, 0, A_LRELU}, nm);
+        if (rc) return rc;
+        x = b(Bb[l]);
+        if (l < 3) {
+            snprintf(nm, sizeof nm, "fnet.pool%d", l + 1);
+            const double bytes = (double)B * lv[l].H * lv[l].W * ch[l] * (bf ? 2 : 4) * 1.25;
+            ProfScope ps(c, nm, 0, bytes);
+            LAUNCHCHK(c, nm, launch_maxpool2(x, b(Pn[l + 1]), bf, B, lv[l].H, lv[l].W, ch[l], st));
+            x = b(Pn[l + 1]);
+        }
+    }
+    // decoder
+    for (int l = 2; l >= 0; --l) {
+        snprintf(nm, sizeof nm, "fnet.resize%d", 3 - l);
+        {
+            const double bytes = (double)B * lv[l + 1].H * lv[l + 1].W * ch[l + 1] * (bf ? 2 : 4) * 5.0;
+            ProfScope ps(c, nm, 0, bytes);
+            LAUNCHCHK(c, nm, launch_resize2x(x, b(Un[l]), bf, B, lv[l + 1].H, lv[l + 1].W, ch[l + 1], st));
+        }
+        x = b(Un[l]);
+        if (l > 0) {
+            snprintf(nm, sizeof nm, "fnet.conv%d", k + 1);
+            int rc = run_conv(c, P, st, c->fnet[k++], B, {x, lv[l].H, lv[l].W, b(A[l]), ch[l], ch[l], af, nullptr, 0, A_LRELU}, nm);
+            if (rc) return rc;
+            snprintf(nm, sizeof nm, "fnet.conv%d", k + 1);
+            rc = run_conv(c, P, st, c->fnet[k++], B, {b(A[l]), lv[l].H, lv[l].W, b(Bb[l]), ch[l], ch[l], af, nullptr, 0, A_LRELU}, nm);
+            if (rc) return rc;
+            x = b(Bb[l]);
+        }
+    }
+    int rc = run_conv(c, P, st, c->fnet[12], B, {x, H, W, b("a0"), 32, 32, af, nullptr, 0, A_LRELU}, "fnet.conv13");
+    if (rc) return rc;
+    return run_conv(c, P, st, c->fnet[13], B, {b("a0"), H, W, d_flow, 2, 2, 1, nullptr, 0, A_TANH}, "fnet.conv14");
+}
+
+// SRNet: reference layers.py:66-76; input already concatenated into buf "s_in"
+int run_srnet(sr_ctx* c, int B, float* d_out) {
+    const int P = c->prec, af = c->prec == P_BF16 ? 0 : 1;
+    hipStream_t st = c->stream;
+    const int H = c->h, W = c->w;
+    auto b = [&](const char* n) { return c->buf[n]; };
+    int rc = run_conv(c, P, st, c->srnet[0], B, {b("s_in"), H, W, b("sx"), 64, 64, af, nullptr, 0, A_RELU}, "srnet.head");
+    if (rc) return rc;
+    for (int r = 0; r < 10; ++r) {
+        rc = run_conv(c, P, st, c->srnet[1 + 2 * r], B, {b("sx"), H, W, b("sy"), 64, 64, af, nullptr, 0, A_RELU}, "srnet.res");
+        if (rc) return rc;
+        // x = x + conv(y): each thread reads then writes its own element, in place is safe
+        rc = run_conv(c, P, st, c->srnet[2 + 2 * r], B, {b("sy"), H, W, b("sx"), 64, 64, af, b("sx"), 64, A_NONE}, "srnet.res");
+        if (rc) return rc;
+    }
+    rc = run_conv(c, P, st, c->srnet[21], B, {b("sx"), H, W, b("up1"), 64, 64, af, nullptr, 0, A_RELU}, "srnet.up1");
+    if (rc) return rc;
+    rc = run_conv(c, P, st, c->srnet[22], B, {b("up1"), 2 * H, 2 * W, b("up2"), 64, 64, af, nullptr, 0, A_RELU}, "srnet.up2");
+    if (rc) return rc;
+    return run_conv(c, P, st, c->srnet[23], B, {b("up2"), 4 * H, 4 * W, d_out, 3, 3, 1, nullptr, 0, A_CLIP01}, "srnet.out");
+}
+
+// one generator step on device buffers (reference FRVSR.py:58-63, TecoGAN.py:68-76)
+int run_step(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, const float* d_est_prev,
+             float* d_est_out, float* d_lr_warp, float* d_hr_warp, bool warp_only) {
+    const int bf = c->prec == P_BF16;
+    const int H = c->h, W = c->w;
+    hipStream_t st = c->stream;
+    int rc = run_fnet(c, B, d_lr_t, d_lr_tm1, c->d_flow);
+    if (rc) return rc;
+    if (d_lr_warp) {
+        ProfScope ps(c, "lr_warp", 0, (double)B * H * W * 4 * (3 + 2 + 3));
+        LAUNCHCHK(c, "lr_warp", launch_warp3(d_lr_tm1, c->d_flow, d_lr_warp, B, H, W, st));
+    }
+    {
+        // algorithmic bytes per LR pixel: read 2 flow + 48 prev-est + 3 LR (fp32), write 64 activations
+        const double bytes = (double)B * H * W * (4.0 * (2 + 48 + 3) + 64.0 * (bf ? 2 : 4) + (d_hr_warp ? 192.0 : 0.0));
+        ProfScope ps(c, "pre_srnet", 0, bytes);
+        LAUNCHCHK(c, "pre_srnet", launch_pre_srnet(c->d_flow, d_est_prev, d_lr_t, c->buf["s_in"], d_hr_warp, bf, B, H, W, st));
+    }
+    if (warp_only) return SR_OK;
+    rc = run_srnet(c, B, d_est_out);
+    if (rc) return rc;
+    if (c->model == SR_TECOGAN) {
+        ProfScope ps(c, "teco_epilogue", 0, (double)B * H * W * (12.0 + 2 * 192.0));
+        LAUNCHCHK(c, "teco_epilogue", launch_teco_epilogue(d_est_out, d_lr_t, B, H, W, st));
+    }
+    return SR_OK;
+}
+
+}  // namespace
+
+// =============================================================== C ABI
+extern "C" {
+
+const char* sr_last_error(const sr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int sr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sr_create(sr_ctx** out, int device, int h, int w, int ch, int scale, int max_batch, int dtype, int model) {
+    if (!out) return fail(nullptr, SR_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (ch != 3) return fail(nullptr, SR_ERR_SHAPE, "channels must be 3, got %d", ch);
+    if (scale != 4) return fail(nullptr, SR_ERR_SHAPE, "upscale must be 4, got %d", scale);
+    if (h < 8 || w < 8 || h % 8 || w % 8)
+        return fail(nullptr, SR_ERR_SHAPE, "LR tile %dx%d: height and width must be multiples of 8 "
+                    "(FNet pools 3x and upsamples 3x; reference layers.py:31-41)", h, w);
+    if (max_batch < 1) return fail(nullptr, SR_ERR_ARG, "max_batch must be >= 1");
+    if (dtype < 0 || dtype > 2) return fail(nullptr, SR_ERR_ARG, "dtype must be 0 (fp32), 1 (bf16) or 2 (bf16x3)");
+    if (model != SR_FRVSR && model != SR_TECOGAN) return fail(nullptr, SR_ERR_ARG, "model must be 0 (frvsr) or 1 (tecogan)");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, SR_ERR_HIP, "no HIP device available (%s); libsr_hip has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, SR_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+    sr_ctx* c = new sr_ctx();
+    c->device = device;
+    c->h = h;
+    c->w = w;
+    c->max_batch = max_batch;
+    c->prec = dtype;
+    c->model = model;
+    int rc = SR_OK;
+    auto bail = [&](int code) {
+        g_err = c->err;
+        sr_destroy(c);
+        return code;
+    };
+    if (hipSetDevice(device) != hipSuccess) return bail(fail(c, SR_ERR_HIP, "hipSetDevice(%d) failed", device));
+    if (hipStreamCreate(&c->stream) != hipSuccess) return bail(fail(c, SR_ERR_HIP, "hipStreamCreate failed"));
+    c->own_stream = true;
+    const size_t es = dtype == SR_BF16 ? 2 : 4;
+    const size_t B = max_batch, L0 = (size_t)h * w, L1 = L0 / 4, L2 = L0 / 16, L3 = L0 / 64;
+    struct { const char* n; size_t elems; } plan[] = {
+        {"x0", L0 * 16}, {"a0", L0 * 32}, {"b0", L0 * 32}, {"p1", L1 * 32}, {"a1", L1 * 64}, {"b1", L1 * 64},
+        {"p2", L2 * 64}, {"a2", L2 * 128}, {"b2", L2 * 128}, {"p3", L3 * 128}, {"a3", L3 * 256}, {"b3", L3 * 256},
+        {"u2", L2 * 256}, {"u1", L1 * 128}, {"u0", L0 * 64},
+        {"s_in", L0 * 64}, {"sx", L0 * 64}, {"sy", L0 * 64}, {"up1", L0 * 4 * 64}, {"up2", L0 * 16 * 64}};
+    for (auto& p : plan)
+        if ((rc = alloc_buf(c, p.n, B * p.elems * es))) return bail(rc);
+    struct { float** p; size_t elems; } fplan[] = {
+        {&c->d_lr_t, L0 * 3}, {&c->d_lr_tm1, L0 * 3}, {&c->d_est[0], L0 * 48}, {&c->d_est[1], L0 * 48},
+        {&c->d_flow, L0 * 2}, {&c->d_lr_warp, L0 * 3}, {&c->d_hr_warp, L0 * 48}, {&c->d_ss, L0 * 48}};
+    for (auto& p : fplan) {
+        if (hipMalloc((void**)p.p, B * p.elems * 4) != hipSuccess)
+            return bail(fail(c, SR_ERR_HIP, "hipMalloc of %zu bytes failed", B * p.elems * 4));
+    }
+    *out = c;
+    return SR_OK;
+}
+
+int sr_destroy(sr_ctx* c) {
+    if (!c) return SR_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    prof_resolve(c);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    for (auto& kv : c->buf) (void)hipFree(kv.second);
+    float* fl[] = {c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_flow, c->d_lr_warp, c->d_hr_warp, c->d_ss};
+    for (auto p : fl)
+        if (p) (void)hipFree(p);
+    for (auto& L : c->fnet) free_layer(L);
+    for (auto& L : c->srnet) free_layer(L);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SR_OK;
+}
+
+int sr_set_stream(sr_ctx* c, void* hip_stream) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->own_stream = false;
+    c->stream = (hipStream_t)hip_stream;
+    return SR_OK;
+}
+
+int sr_sync(sr_ctx* c) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SR_OK;
+}
+
+int sr_load_tensor(sr_ctx* c, const char* name, const float* host, const int64_t* shape, int rank) {
+    if (!c || !name || !host || !shape) return fail(c, SR_ERR_ARG, "NULL argument");
+    if (rank != 1 && rank != 4) return fail(c, SR_ERR_WEIGHTS, "%s: rank %d, expected 1 (bias) or 4 (kernel)", name, rank);
+    const bool is_f = strncmp(name, "FNet/", 5) == 0, is_s = strncmp(name, "SRNet/", 6) == 0;
+    if (!is_f && !is_s) return fail(c, SR_ERR_WEIGHTS, "%s: tensor name must start with FNet/ or SRNet/", name);
+    if (c->committed) {   // a new load_weights after a commit starts over
+        c->tensors.clear();
+        c->n_fnet = c->n_srnet = 0;
+        c->committed = false;
+    }
+    if (is_f && c->n_srnet) return fail(c, SR_ERR_WEIGHTS, "%s: FNet tensors must precede SRNet tensors", name);
+    int& n = is_f ? c->n_fnet : c->n_srnet;
+    const int lim = is_f ? 28 : 48;
+    if (n >= lim) return fail(c, SR_ERR_WEIGHTS, "%s: more than %d tensors in group", name, lim);
+    const int layer = n / 2;
+    const bool is_kernel = (n % 2) == 0;
+    int cin, cout, mode = M_CONV;
+    if (is_f) {
+        cin = FNET_SPEC[layer][0];
+        cout = FNET_SPEC[layer][1];
+    } else {
+        srnet_spec(layer, cin, cout, mode);
+    }
+    if (is_kernel) {
+        const int64_t want[4] = {3, 3, mode == M_CONV ? cin : cout, mode == M_CONV ? cout : cin};
+        if (rank != 4 || memcmp(shape, want, sizeof want))
+            return fail(c, SR_ERR_WEIGHTS, "%s: position %d of its group expects a kernel of shape (3,3,%lld,%lld)",
+                        name, n, (long long)want[2], (long long)want[3]);
+    } else if (rank != 1 || shape[0] != cout) {
+        return fail(c, SR_ERR_WEIGHTS, "%s: position %d of its group expects a bias of shape (%d,)", name, n, cout);
+    }
+    HostTensor t;
+    t.name = name;
+    t.shape.assign(shape, shape + rank);
+    size_t cnt = 1;
+    for (int i = 0; i < rank; ++i) cnt *= (size_t)shape[i];
+    t.data.assign(host, host + cnt);
+    c->tensors.push_back(std::move(t));
+    ++n;
+    return SR_OK;
+}
+
+int sr_commit_weights(sr_ctx* c) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    if (c->n_fnet != 28 || c->n_srnet != 48)
+        return fail(c, SR_ERR_WEIGHTS, "expected 28 FNet + 48 SRNet tensors, have %d + %d", c->n_fnet, c->n_srnet);
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int i = 0; i < 14; ++i) {
+        plan_layer(c->fnet[i], c->prec, M_CONV, FNET_SPEC[i][0], FNET_SPEC[i][1]);
+        int rc = upload_layer(c, c->fnet[i], c->prec, c->tensors[2 * i].data.data(), c->tensors[2 * i + 1].data.data());
+        if (rc) return rc;
+    }
+    for (int i = 0; i < 24; ++i) {
+        int cin, cout, mode;
+        srnet_spec(i, cin, cout, mode);
+        plan_layer(c->srnet[i], c->prec, mode, cin, cout);
+        int rc = upload_layer(c, c->srnet[i], c->prec, c->tensors[28 + 2 * i].data.data(), c->tensors[28 + 2 * i + 1].data.data());
+        if (rc) return rc;
+    }
+    c->committed = true;
+    return SR_OK;
+}
+
+int sr_get_tensor(const sr_ctx* c, int index, char* name_out, int name_cap, float* host_out, int64_t* shape_out, int* rank_out) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    if (index < 0 || index >= (int)c->tensors.size()) return fail(nullptr, SR_ERR_ARG, "tensor index %d out of range", index);
+    const HostTensor& t = c->tensors[index];
+    if (name_out && name_cap > 0) snprintf(name_out, name_cap, "%s", t.name.c_str());
+    if (rank_out) *rank_out = (int)t.shape.size();
+    if (shape_out) memcpy(shape_out, t.shape.data(), t.shape.size() * sizeof(int64_t));
+    if (host_out) memcpy(host_out, t.data.data(), t.data.size() * 4);
+    return SR_OK;
+}
+
+int sr_step_dev(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1, float* est_t, float* lr_warp) {
+    int rc = check_ready(c, B);
+    if (rc) return rc;
+    if (!lr_t || !lr_tm1 || !est_tm1 || !est_t) return fail(c, SR_ERR_ARG, "NULL tensor pointer");
+    return run_step(c, B, lr_t, lr_tm1, est_tm1, est_t, lr_warp, nullptr, false);
+}
+
+int sr_step(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1, float* est_t, float* lr_warp) {
+    int rc = check_ready(c, B);
+    if (rc) return rc;
+    if (!lr_t || !lr_tm1 || !est_tm1 || !est_t) return fail(c, SR_ERR_ARG, "NULL tensor pointer");
+    c->clip_active = false;   // the stateless step borrows the state buffers
+    const size_t nlr = (size_t)B * c->h * c->w * 3 * 4, nhr = nlr * 16;
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, lr_tm1, nlr, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, hipMemcpyHostToDevice, st));
+    rc = run_step(c, B, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], lr_warp ? c->d_lr_warp : nullptr, nullptr, false);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(est_t, c->d_est[1], nhr, hipMemcpyDeviceToHost, st));
+    if (lr_warp) HIPCHK(c, hipMemcpyAsync(lr_warp, c->d_lr_warp, nlr, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return SR_OK;
+}
+
+int sr_step_hr_warp(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1, float* hr_warp) {
+    int rc = check_ready(c, B);
+    if (rc) return rc;
+    if (!lr_t || !lr_tm1 || !est_tm1 || !hr_warp) return fail(c, SR_ERR_ARG, "NULL tensor pointer");
+    c->clip_active = false;
+    const size_t nlr = (size_t)B * c->h * c->w * 3 * 4, nhr = nlr * 16;
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, lr_tm1, nlr, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, hipMemcpyHostToDevice, st));
+    rc = run_step(c, B, c->d_lr_t, c->d_lr_tm1, c->d_est[0], nullptr, nullptr, c->d_hr_warp, true);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(hr_warp, c->d_hr_warp, nhr, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return SR_OK;
+}
+
+int sr_clip_begin(sr_ctx* c, int B) {
+    int rc = check_ready(c, B);
+    if (rc) return rc;
+    const size_t nlr = (size_t)B * c->h * c->w * 3 * 4;
+    // state0 = zeros for prev LR and prev estimate (reference FRVSR.py:233-234)
+    HIPCHK(c, hipMemsetAsync(c->d_lr_tm1, 0, nlr, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_est[0], 0, nlr * 16, c->stream));
+    c->cur = 0;
+    c->clip_B = B;
+    c->clip_active = true;
+    return SR_OK;
+}
+
+static int clip_push_common(sr_ctx* c, const float* lr_t, float* est_t, bool dev) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    if (!c->clip_active) return fail(c, SR_ERR_STATE, "sr_clip_push without sr_clip_begin");
+    if (!lr_t) return fail(c, SR_ERR_ARG, "lr_t is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int B = c->clip_B;
+    const size_t nlr = (size_t)B * c->h * c->w * 3 * 4, nhr = nlr * 16;
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    float* out = c->d_est[c->cur ^ 1];
+    int rc = run_step(c, B, c->d_lr_t, c->d_lr_tm1, c->d_est[c->cur], out, nullptr, nullptr, false);
+    if (rc) return rc;
+    // est state := output, prev LR := current (reference FRVSR.py:293,309)
+    c->cur ^= 1;
+    float* t = c->d_lr_t;
+    c->d_lr_t = c->d_lr_tm1;
+    c->d_lr_tm1 = t;
+    if (est_t) HIPCHK(c, hipMemcpyAsync(est_t, out, nhr, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    if (!dev) HIPCHK(c, hipStreamSynchronize(st));
+    return SR_OK;
+}
+
+int sr_clip_push(sr_ctx* c, const float* lr_t, float* est_t) { return clip_push_common(c, lr_t, est_t, false); }
+int sr_clip_push_dev(sr_ctx* c, const float* lr_t, float* est_t) { return clip_push_common(c, lr_t, est_t, true); }
+
+int sr_fnet(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, float* flow) {
+    int rc = check_ready(c, B);
+    if (rc) return rc;
+    if (!lr_t || !lr_tm1 || !flow) return fail(c, SR_ERR_ARG, "NULL tensor pointer");
+    c->clip_active = false;
+    const size_t nlr = (size_t)B * c->h * c->w * 3 * 4;
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, lr_tm1, nlr, hipMemcpyHostToDevice, st));
+    rc = run_fnet(c, B, c->d_lr_t, c->d_lr_tm1, c->d_flow);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(flow, c->d_flow, nlr / 3 * 2, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return SR_OK;
+}
+
+int sr_srnet(sr_ctx* c, int B, const float* lr_t, const float* s_s, float* out) {
+    int rc = check_ready(c, B);
+    if (rc) return rc;
+    if (!lr_t || !s_s || !out) return fail(c, SR_ERR_ARG, "NULL tensor pointer");
+    c->clip_active = false;
+    const size_t nlr = (size_t)B * c->h * c->w * 3 * 4, nhr = nlr * 16;
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_ss, s_s, nhr, hipMemcpyHostToDevice, st));
+    LAUNCHCHK(c, "srnet.input", launch_srnet_input(c->d_lr_t, c->d_ss, c->buf["s_in"], c->prec == P_BF16, B, c->h, c->w, st));
+    rc = run_srnet(c, B, c->d_est[1]);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->d_est[1], nhr, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return SR_OK;
+}
+
+// ---------------------------------------------------------------- profiling
+int sr_profile_enable(sr_ctx* c, int enable) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    c->prof_on = enable != 0;
+    return SR_OK;
+}
+int sr_profile_count(const sr_ctx* c) { return c ? (int)c->prof.size() : 0; }
+int sr_profile_read(sr_ctx* c, int i, char* name_out, int name_cap, double* ms_total, int64_t* launches,
+                    double* flops_per_launch, double* bytes_per_launch) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    if (i < 0 || i >= (int)c->prof.size()) return fail(c, SR_ERR_ARG, "profile index out of range");
+    (void)hipSetDevice(c->device);
+    prof_resolve(c);
+    const ProfEntry& p = c->prof[i];
+    if (name_out && name_cap > 0) snprintf(name_out, name_cap, "%s", p.name.c_str());
+    if (ms_total) *ms_total = p.ms;
+    if (launches) *launches = p.launches;
+    if (flops_per_launch) *flops_per_launch = p.flops;
+    if (bytes_per_launch) *bytes_per_launch = p.bytes;
+    return SR_OK;
+}
+int sr_profile_reset(sr_ctx* c) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    (void)hipSetDevice(c->device);
+    prof_resolve(c);
+    c->prof.clear();
+    return SR_OK;
+}
+
+// ---------------------------------------------------------------- single ops
+namespace {
+struct DevBufs {
+    std::vector<void*> p;
+    ~DevBufs() {
+        for (auto q : p) (void)hipFree(q);
+    }
+    void* get(size_t bytes) {
+        void* q = nullptr;
+        if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) return nullptr;
+        p.push_back(q);
+        return q;
+    }
+};
+
+int op_prologue(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, SR_ERR_HIP, "no HIP device available; libsr_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(nullptr, SR_ERR_ARG, "device %d out of range", device);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, SR_ERR_HIP, "hipSetDevice failed");
+    return SR_OK;
+}
+
+int conv_op(int device, int dtype, int mode, int B, int H, int W, int Cin, int Cout, const float* x, const float* w,
+            const float* bias, int act, const float* res, float* out) {
+    int rc = op_prologue(device);
+    if (rc) return rc;
+    if (!x || !w || !bias || !out) return fail(nullptr, SR_ERR_ARG, "NULL tensor pointer");
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return fail(nullptr, SR_ERR_ARG, "non-positive dimension");
+    if (dtype < 0 || dtype > 2) return fail(nullptr, SR_ERR_ARG, "bad dtype");
+    if (act < 0 || act > 4) return fail(nullptr, SR_ERR_ARG, "bad activation");
+    ConvLayer L;
+    plan_layer(L, dtype, mode, Cin, Cout);
+    struct Guard { ConvLayer& l; ~Guard() { free_layer(l); } } guard{L};
+    if ((rc = upload_layer(nullptr, L, dtype, w, bias))) return rc;
+    DevBufs d;
+    const size_t npix = (size_t)B * H * W, opix = mode == M_CONV ? npix : 4 * npix;
+    const size_t es = dtype == SR_BF16 ? 2 : 4;
+    float* d_x = (float*)d.get(npix * Cin * 4);
+    void* d_xp = d.get(npix * L.cin_p * es);
+    float* d_out = (float*)d.get(opix * Cout * 4);
+    float* d_res = res ? (float*)d.get(opix * Cout * 4) : nullptr;
+    if (!d_x || !d_xp || !d_out || (res && !d_res)) return fail(nullptr, SR_ERR_HIP, "hipMalloc failed");
+    HIPCHK(nullptr, hipMemcpy(d_x, x, npix * Cin * 4, hipMemcpyHostToDevice));
+    if (res) HIPCHK(nullptr, hipMemcpy(d_res, res, opix * Cout * 4, hipMemcpyHostToDevice));
+    LAUNCHCHK(nullptr, "pad_channels", launch_pad_channels(d_x, d_xp, dtype == SR_BF16, (long)npix, Cin, L.cin_p, nullptr));
+    rc = run_conv(nullptr, dtype, nullptr, L, B, {d_xp, H, W, d_out, Cout, Cout, 1, d_res, Cout, act}, "op_conv");
+    if (rc) return rc;
+    HIPCHK(nullptr, hipDeviceSynchronize());
+    HIPCHK(nullptr, hipMemcpy(out, d_out, opix * Cout * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+typedef hipError_t (*simple_launch)(const float*, float*, int, int, int, int, hipStream_t);
+
+int simple_op(int device, size_t in_elems, size_t out_elems, const float* x, float* out,
+              const std::function<hipError_t(const float*, float*)>& fn) {
+    int rc = op_prologue(device);
+    if (rc) return rc;
+    if (!x || !out) return fail(nullptr, SR_ERR_ARG, "NULL tensor pointer");
+    DevBufs d;
+    float* d_x = (float*)d.get(in_elems * 4);
+    float* d_o = (float*)d.get(out_elems * 4);
+    if (!d_x || !d_o) return fail(nullptr, SR_ERR_HIP, "hipMalloc failed");
+    HIPCHK(nullptr, hipMemcpy(d_x, x, in_elems * 4, hipMemcpyHostToDevice));
+    LAUNCHCHK(nullptr, "op", fn(d_x, d_o));
+    HIPCHK(nullptr, hipDeviceSynchronize());
+    HIPCHK(nullptr, hipMemcpy(out, d_o, out_elems * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+}  // namespace
+
+int sr_op_conv3x3(int device, int dtype, int B, int H, int W, int Cin, int Cout, const float* x, const float* w,
+                  const float* bias, int act, const float* res, float* out) {
+    return conv_op(device, dtype, M_CONV, B, H, W, Cin, Cout, x, w, bias, act, res, out);
+}
+
+int sr_op_convT3x3s2(int device, int dtype, int B, int H, int W, int Cin, int Cout, const float* x, const float* w,
+                     const float* bias, int act, float* out) {
+    return conv_op(device, dtype, M_CONVT, B, H, W, Cin, Cout, x, w, bias, act, nullptr, out);
+}
+
+int sr_op_maxpool2(int device, int B, int H, int W, int C, const float* x, float* out) {
+    if (B < 1 || H < 1 || W < 1 || C < 1) return fail(nullptr, SR_ERR_ARG, "non-positive dimension");
+    const size_t n_in = (size_t)B * H * W * C, n_out = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * C;
+    return simple_op(device, n_in, n_out, x, out, [&](const float* a, float* o) {
+        // channel counts the hot path uses go through the vectorised kernel
+        return C % 4 == 0 ? launch_maxpool2(a, o, 0, B, H, W, C, nullptr) : launch_maxpool2_generic(a, o, B, H, W, C, nullptr);
+    });
+}
+
+int sr_op_resize_bilinear(int device, int B, int H, int W, int C, int s, const float* x, float* out) {
+    if (B < 1 || H < 1 || W < 1 || C < 1 || s < 1) return fail(nullptr, SR_ERR_ARG, "non-positive dimension");
+    const size_t n_in = (size_t)B * H * W * C;
+    return simple_op(device, n_in, n_in * s * s, x, out, [&](const float* a, float* o) {
+        return (s == 2 && C % 4 == 0) ? launch_resize2x(a, o, 0, B, H, W, C, nullptr)
+                                      : launch_resize_generic(a, o, B, H, W, C, s, nullptr);
+    });
+}
+
+int sr_op_warp(int device, int B, int H, int W, int C, const float* img, const float* flow, float* out) {
+    if (B < 1 || H < 2 || W < 2 || C < 1) return fail(nullptr, SR_ERR_ARG, "dense_image_warp needs H, W >= 2");
+    if (!flow) return fail(nullptr, SR_ERR_ARG, "NULL tensor pointer");
+    int rc = op_prologue(device);
+    if (rc) return rc;
+    DevBufs d;
+    const size_t npix = (size_t)B * H * W;
+    float* d_f = (float*)d.get(npix * 2 * 4);
+    if (!d_f) return fail(nullptr, SR_ERR_HIP, "hipMalloc failed");
+    HIPCHK(nullptr, hipMemcpy(d_f, flow, npix * 2 * 4, hipMemcpyHostToDevice));
+    return simple_op(device, npix * C, npix * C, img, out, [&](const float* a, float* o) {
+        return launch_warp_generic(a, d_f, o, B, H, W, C, nullptr);
+    });
+}
+
+int sr_op_space_to_depth(int device, int B, int H, int W, int C, int bs, const float* x, float* out) {
+    if (B < 1 || H < 1 || W < 1 || C < 1 || bs < 1) return fail(nullptr, SR_ERR_ARG, "non-positive dimension");
+    if (H % bs || W % bs) return fail(nullptr, SR_ERR_SHAPE, "space_to_depth: H and W must be multiples of the block size");
+    const size_t n = (size_t)B * H * W * C;
+    return simple_op(device, n, n, x, out, [&](const float* a, float* o) {
+        return launch_s2d_generic(a, o, B, H, W, C, bs, nullptr);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,299 @@
+"""ctypes binding of libsr_hip.so (C ABI in include/sr_hip.h).
+
+This is the only place Python touches the native library.  There is no CPU
+fallback: if the library or a HIP device is missing, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsr_hip.so")
+
+FP32, BF16, BF16X3 = 0, 1, 2
+DTYPES = {"fp32": FP32, "float32": FP32, "bf16": BF16, "bfloat16": BF16, "bf16x3": BF16X3}
+FRVSR, TECOGAN = 0, 1
+ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2, "leaky_relu": 2, "tanh": 3, "clip01": 4}
+
+_f32p = C.POINTER(C.c_float)
+_i64p = C.POINTER(C.c_int64)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/sr_hip.h declares
+SIGNATURES = {
+    "sr_last_error": (C.c_char_p, [_vp]),
+    "sr_device_count": (C.c_int, []),
+    "sr_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sr_destroy": (C.c_int, [_vp]),
+    "sr_set_stream": (C.c_int, [_vp, _vp]),
+    "sr_sync": (C.c_int, [_vp]),
+    "sr_load_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64p, C.c_int]),
+    "sr_commit_weights": (C.c_int, [_vp]),
+    "sr_get_tensor": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, _vp, _i64p, C.POINTER(C.c_int)]),
+    "sr_step": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "sr_step_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "sr_step_hr_warp": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "sr_clip_begin": (C.c_int, [_vp, C.c_int]),
+    "sr_clip_push": (C.c_int, [_vp, _vp, _vp]),
+    "sr_clip_push_dev": (C.c_int, [_vp, _vp, _vp]),
+    "sr_fnet": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "sr_srnet": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "sr_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "sr_profile_count": (C.c_int, [_vp]),
+    "sr_profile_read": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), _i64p,
+                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "sr_profile_reset": (C.c_int, [_vp]),
+    "sr_op_conv3x3": (C.c_int, [C.c_int] * 7 + [_vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "sr_op_convT3x3s2": (C.c_int, [C.c_int] * 7 + [_vp, _vp, _vp, C.c_int, _vp]),
+    "sr_op_maxpool2": (C.c_int, [C.c_int] * 5 + [_vp, _vp]),
+    "sr_op_resize_bilinear": (C.c_int, [C.c_int] * 6 + [_vp, _vp]),
+    "sr_op_warp": (C.c_int, [C.c_int] * 5 + [_vp, _vp, _vp]),
+    "sr_op_space_to_depth": (C.c_int, [C.c_int] * 6 + [_vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libsr_hip.so once (loudly: a missing library is an error, never a fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C super-resolution_amd/csrc` (there is no CPU fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def _err(ctx):
+    return lib().sr_last_error(ctx).decode("utf-8", "replace")
+
+
+def _check(rc, ctx=None):
+    if rc == 0:
+        return
+    msg = _err(ctx)
+    # SR_ERR_ARG / SHAPE / WEIGHTS -> ValueError (Keras raises ValueError on shape mismatch); rest RuntimeError
+    if rc in (-1, -2, -3):
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp)
+
+
+def device_count() -> int:
+    return lib().sr_device_count()
+
+
+class Context:
+    """One generator (FNet + SRNet + warps) for LR tiles of (h, w, 3) on one GPU."""
+
+    def __init__(self, h, w, ch=3, scale=4, max_batch=1, dtype="fp32", model="frvsr", device=0):
+        self.h, self.w, self.max_batch = int(h), int(w), int(max_batch)
+        self.dtype = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+        self.model = {"frvsr": FRVSR, "tecogan": TECOGAN}[model] if isinstance(model, str) else int(model)
+        self._h = _vp()
+        _check(lib().sr_create(C.byref(self._h), device, h, w, ch, scale, max_batch, self.dtype, self.model))
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        _check(lib().sr_set_stream(self._h, _vp(stream_ptr)), self._h)
+
+    def sync(self):
+        _check(lib().sr_sync(self._h), self._h)
+
+    # -- weights
+    def load_weights(self, tensors):
+        """tensors: ordered mapping / iterable of (keras_name, array), file order."""
+        items = tensors.items() if hasattr(tensors, "items") else tensors
+        for name, arr in items:
+            a = _f32(arr)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            _check(lib().sr_load_tensor(self._h, name.encode(), _ptr(a), shape, a.ndim), self._h)
+        _check(lib().sr_commit_weights(self._h), self._h)
+
+    def get_weights(self):
+        out = []
+        name = C.create_string_buffer(256)
+        shape = (C.c_int64 * 4)()
+        rank = C.c_int()
+        i = 0
+        while lib().sr_get_tensor(self._h, i, name, 256, None, shape, C.byref(rank)) == 0:
+            a = np.empty(tuple(shape[: rank.value]), np.float32)
+            _check(lib().sr_get_tensor(self._h, i, None, 0, _ptr(a), None, None), self._h)
+            out.append((name.value.decode(), a))
+            i += 1
+        return out
+
+    # -- compute
+    def _shapes(self, B):
+        return (B, self.h, self.w, 3), (B, 4 * self.h, 4 * self.w, 3)
+
+    def _check_in(self, a, shape, what):
+        a = _f32(a)
+        if a.shape != shape:
+            raise ValueError(f"{what}: expected shape {shape}, got {a.shape}")
+        return a
+
+    def step(self, lr_t, lr_tm1, est_tm1, want_lr_warp=True):
+        B = int(np.shape(lr_t)[0])
+        ls, hs = self._shapes(B)
+        lr_t, lr_tm1 = self._check_in(lr_t, ls, "I_LR_t"), self._check_in(lr_tm1, ls, "I_LR_t_1")
+        est_tm1 = self._check_in(est_tm1, hs, "I_est_t_1")
+        est = np.empty(hs, np.float32)
+        lw = np.empty(ls, np.float32) if want_lr_warp else None
+        _check(lib().sr_step(self._h, B, _ptr(lr_t), _ptr(lr_tm1), _ptr(est_tm1), _ptr(est),
+                             _ptr(lw) if want_lr_warp else None), self._h)
+        return est, lw
+
+    def step_dev(self, B, lr_t, lr_tm1, est_tm1, est_t, lr_warp=None):
+        """Device pointers (ints), asynchronous on the ctx stream."""
+        _check(lib().sr_step_dev(self._h, B, _vp(lr_t), _vp(lr_tm1), _vp(est_tm1), _vp(est_t),
+                                 _vp(lr_warp) if lr_warp else None), self._h)
+
+    def hr_warp(self, lr_t, lr_tm1, est_tm1):
+        B = int(np.shape(lr_t)[0])
+        ls, hs = self._shapes(B)
+        lr_t, lr_tm1 = self._check_in(lr_t, ls, "I_LR_t"), self._check_in(lr_tm1, ls, "I_LR_t_1")
+        est_tm1 = self._check_in(est_tm1, hs, "I_est_t_1")
+        out = np.empty(hs, np.float32)
+        _check(lib().sr_step_hr_warp(self._h, B, _ptr(lr_t), _ptr(lr_tm1), _ptr(est_tm1), _ptr(out)), self._h)
+        return out
+
+    def clip_begin(self, B):
+        self._clip_B = int(B)
+        _check(lib().sr_clip_begin(self._h, B), self._h)
+
+    def clip_push(self, lr_t, want_output=True):
+        B = getattr(self, "_clip_B", 0)
+        ls, hs = self._shapes(B)
+        lr_t = self._check_in(lr_t, ls, "I_LR_t")
+        out = np.empty(hs, np.float32) if want_output else None
+        _check(lib().sr_clip_push(self._h, _ptr(lr_t), _ptr(out) if want_output else None), self._h)
+        return out
+
+    def clip_push_dev(self, lr_t, est_t=None):
+        _check(lib().sr_clip_push_dev(self._h, _vp(lr_t), _vp(est_t) if est_t else None), self._h)
+
+    def fnet(self, lr_t, lr_tm1):
+        B = int(np.shape(lr_t)[0])
+        ls, _ = self._shapes(B)
+        lr_t, lr_tm1 = self._check_in(lr_t, ls, "I_LR_t"), self._check_in(lr_tm1, ls, "I_LR_t_1")
+        flow = np.empty((B, self.h, self.w, 2), np.float32)
+        _check(lib().sr_fnet(self._h, B, _ptr(lr_t), _ptr(lr_tm1), _ptr(flow)), self._h)
+        return flow
+
+    def srnet(self, lr_t, s_s):
+        B = int(np.shape(lr_t)[0])
+        ls, hs = self._shapes(B)
+        lr_t = self._check_in(lr_t, ls, "I_LR_t")
+        s_s = self._check_in(s_s, (B, self.h, self.w, 48), "S_s")
+        out = np.empty(hs, np.float32)
+        _check(lib().sr_srnet(self._h, B, _ptr(lr_t), _ptr(s_s), _ptr(out)), self._h)
+        return out
+
+    # -- profiling
+    def profile_enable(self, on=True):
+        _check(lib().sr_profile_enable(self._h, 1 if on else 0), self._h)
+
+    def profile_reset(self):
+        _check(lib().sr_profile_reset(self._h), self._h)
+
+    def profile_read(self):
+        """[{name, ms_total, launches, flops_per_launch, bytes_per_launch}]"""
+        out = []
+        name = C.create_string_buffer(128)
+        ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+        n = C.c_int64()
+        for i in range(lib().sr_profile_count(self._h)):
+            _check(lib().sr_profile_read(self._h, i, name, 128, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), self._h)
+            out.append(dict(name=name.value.decode(), ms_total=ms.value, launches=n.value,
+                            flops_per_launch=fl.value, bytes_per_launch=by.value))
+        return out
+
+
+# ---------------------------------------------------------------- single ops
+def conv3x3(x, w, b, act="none", res=None, dtype="fp32", device=0):
+    x, w, b = _f32(x), _f32(w), _f32(b)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[3]
+    if w.shape != (3, 3, Cin, Cout) or b.shape != (Cout,):
+        raise ValueError(f"kernel {w.shape} / bias {b.shape} do not match input channels {Cin}")
+    out = np.empty((B, H, W, Cout), np.float32)
+    r = _f32(res) if res is not None else None
+    _check(lib().sr_op_conv3x3(device, DTYPES[dtype], B, H, W, Cin, Cout, _ptr(x), _ptr(w), _ptr(b), ACT[act],
+                               _ptr(r) if r is not None else None, _ptr(out)))
+    return out
+
+
+def conv_transpose3x3_s2(x, w, b, act="none", dtype="fp32", device=0):
+    x, w, b = _f32(x), _f32(w), _f32(b)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[2]
+    if w.shape != (3, 3, Cout, Cin) or b.shape != (Cout,):
+        raise ValueError(f"kernel {w.shape} / bias {b.shape} do not match input channels {Cin}")
+    out = np.empty((B, 2 * H, 2 * W, Cout), np.float32)
+    _check(lib().sr_op_convT3x3s2(device, DTYPES[dtype], B, H, W, Cin, Cout, _ptr(x), _ptr(w), _ptr(b), ACT[act], _ptr(out)))
+    return out
+
+
+def maxpool2(x, device=0):
+    x = _f32(x)
+    B, H, W, Cc = x.shape
+    out = np.empty((B, (H + 1) // 2, (W + 1) // 2, Cc), np.float32)
+    _check(lib().sr_op_maxpool2(device, B, H, W, Cc, _ptr(x), _ptr(out)))
+    return out
+
+
+def resize_bilinear(x, s, device=0):
+    x = _f32(x)
+    B, H, W, Cc = x.shape
+    out = np.empty((B, s * H, s * W, Cc), np.float32)
+    _check(lib().sr_op_resize_bilinear(device, B, H, W, Cc, s, _ptr(x), _ptr(out)))
+    return out
+
+
+def warp(img, flow, device=0):
+    img, flow = _f32(img), _f32(flow)
+    B, H, W, Cc = img.shape
+    if flow.shape != (B, H, W, 2):
+        raise ValueError(f"flow shape {flow.shape} does not match image {img.shape}")
+    out = np.empty_like(img)
+    _check(lib().sr_op_warp(device, B, H, W, Cc, _ptr(img), _ptr(flow), _ptr(out)))
+    return out
+
+
+def space_to_depth(x, bs=4, device=0):
+    x = _f32(x)
+    B, H, W, Cc = x.shape
+    if H % bs or W % bs:
+        raise ValueError("space_to_depth: H and W must be multiples of the block size")
+    out = np.empty((B, H // bs, W // bs, bs * bs * Cc), np.float32)
+    _check(lib().sr_op_space_to_depth(device, B, H, W, Cc, bs, _ptr(x), _ptr(out)))
+    return out
