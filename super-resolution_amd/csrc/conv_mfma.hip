@@ -4,16 +4,24 @@
 //
 // Decomposition (one workgroup = 256 threads = 4 wave64):
 //   M = 32-pixel row segments of the output tile (TH rows x 32 columns),
-//   N = NT blocks of 32 output channels, K = 9 taps x input channels.
-//   The (TH+2) x 34 halo tile of one input-channel chunk lives in LDS, pixel
-//   major, each pixel's 32*STEPS payload bytes followed by 16 B of padding so the
-//   32 lanes of an A-fragment read (ds_read_b128, one pixel per lane) fall on 16
-//   distinct 16-B bank slots.  Weights are pre-packed on the host in exactly the
-//   per-lane B-fragment order and stream from L2 with one coalesced 1-KiB
-//   global_load_dwordx4 per (tap, k-step, N block) per wave.
-//   D layout of v_mfma_*_32x32: column (lane & 31) = output channel, the 16
-//   accumulator registers = pixels, so every store instruction writes 32
-//   consecutive channels of one pixel per half-wave.
+//   N = NT blocks of 32 output channels, K = taps x input channels.
+//   The halo tile of one input-channel chunk lives in LDS, pixel major, each
+//   pixel's 32*STEPS payload bytes followed by 16 B of padding so the 32 lanes of
+//   an A-fragment read (ds_read_b128, one pixel per lane) fall on 16 distinct
+//   16-B bank slots.  Weights are pre-packed on the host in exactly the per-lane
+//   B-fragment order and stream from L2 with one coalesced 1-KiB
+//   global_load_dwordx4 per (tap, k-step, N block) per wave, through a register
+//   ring that runs PF k-steps ahead of the MFMAs (the stream is contiguous over
+//   passes, chunks, taps and steps, so the ring never drains inside a tile).
+//   The next chunk's halo tile is fetched into registers while the current
+//   chunk computes.  D layout of v_mfma_*_32x32: column (lane & 31) = output
+//   channel, the 16 accumulator registers = pixels, so every store instruction
+//   writes 32 consecutive channels of one pixel per half-wave.
+//
+//   M_CONV : 8-row tiles, one pass over 9 taps, chunks of 32*STEPS payload bytes.
+//   M_CONVT: out[2i+ky, 2j+kx] += in[i,j] w[ky,kx]  =>  four output phases
+//            (ky&1, kx&1) with 4 / 2 / 2 / 1 taps, run as four passes over ONE
+//            staged 4-row tile (top/left halo only), one accumulator set alive.
 //
 // Precisions: P_FP32   v_mfma_f32_32x32x2_f32, exact fp32 products;
 //             P_BF16   v_mfma_f32_32x32x16_bf16 on bf16 activations;
@@ -54,22 +62,204 @@ __device__ __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b)
 }
 
 template <int PREC, int MODE, int NT, int STEPS>
-__global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
-    constexpr int MT = MODE == M_CONV ? 2 : 1;     // 32-pixel row segments per wave
-    constexpr int TH = 4 * MT;                     // tile rows
-    constexpr int NPH = MODE == M_CONV ? 1 : 4;    // output phases (transposed conv: 2x2)
-    constexpr int NPIX = (TH + 2) * HALO_W;
-    constexpr int PS = 32 * STEPS + 16;            // LDS bytes per halo pixel
-    constexpr int TILE_BYTES = NPIX * PS;
-    constexpr int KS = prec_ks(PREC);
-    constexpr int CKC = STEPS * KS;                // input channels per chunk
-    constexpr bool IN_F32 = PREC != P_BF16;
-    constexpr int ESZ = IN_F32 ? 4 : 2;
-    constexpr int VPP = CKC * ESZ / 16;            // 16-B global vectors per pixel per chunk
-    constexpr int NV = NPIX * VPP;
-    constexpr int ITER = (NV + 255) / 256;
-    constexpr int BV = PREC == P_BF16X3 ? 2 : 1;   // B vectors per (step, N block): hi, lo
+struct Geo {
+    static constexpr int MT = MODE == M_CONV ? 2 : 1;        // 32-pixel row segments per wave
+    static constexpr int TH = 4 * MT;                         // tile rows
+    static constexpr int HB = MODE == M_CONV ? 1 : 0;         // bottom / right halo
+    static constexpr int HROWS = TH + 1 + HB, HCOLS = TW + 1 + HB;
+    static constexpr int NPIX = HROWS * HCOLS;
+    static constexpr int PS = 32 * STEPS + 16;                // LDS bytes per halo pixel
+    static constexpr int TILE_BYTES = NPIX * PS;
+    static constexpr int KS = prec_ks(PREC);
+    static constexpr int CKC = STEPS * KS;                    // input channels per chunk
+    static constexpr int ESZ = PREC == P_BF16 ? 2 : 4;        // bytes per activation element in HBM
+    static constexpr int VPP = CKC * ESZ / 16;                // 16-B global vectors per pixel per chunk
+    static constexpr int NV = NPIX * VPP;
+    static constexpr int ITER = (NV + 255) / 256;
+    static constexpr int BV = PREC == P_BF16X3 ? 2 : 1;       // B vectors per (step, N block): hi, lo
+    static constexpr int AV = PREC == P_BF16X3 ? 2 : 1;       // A vectors per (step, M block): hi, lo
+    static constexpr int STEPV = NT * BV * 64;                // 16-B vectors of packed weights per k-step
+    static constexpr int NPASS = MODE == M_CONV ? 1 : 4;
+    // weight ring: R slots, PF = R-1 steps of prefetch; R divides every pass's step count
+    static constexpr int R = MODE == M_CONV ? ((PREC == P_BF16 && STEPS % 2 == 0) ? 6 : 3)
+                                            : (STEPS % 4 == 0 ? 4 : (STEPS % 2 == 0 ? 2 : 1));
+    static constexpr int PF = R - 1;
+};
 
+__host__ __device__ constexpr int pass_ntaps(int mode, int pass) {
+    return mode == M_CONV ? 9 : (pass == 0 ? 4 : (pass == 3 ? 1 : 2));
+}
+// tap index ky*3+kx of the t-th tap of a pass.  Transposed conv: phase (a,b) = (ky&1, kx&1);
+// pass 0 = (0,0): ky,kx in {0,2}; pass 1 = (0,1): ky in {0,2}, kx=1; pass 2 = (1,0); pass 3 = (1,1).
+__host__ __device__ constexpr int pass_tap(int mode, int pass, int t) {
+    if (mode == M_CONV) return t;
+    if (pass == 0) return t == 0 ? 0 : (t == 1 ? 2 : (t == 2 ? 6 : 8));
+    if (pass == 1) return t == 0 ? 1 : 7;
+    if (pass == 2) return t == 0 ? 3 : 5;
+    return 4;
+}
+
+template <class G, int PREC>
+__device__ __forceinline__ void stage_load(u32x4 (&regs)[G::ITER], const unsigned char* inb, int c, int cin_p,
+                                           int y0, int x0, int H, int W, int tid) {
+#pragma unroll
+    for (int it = 0; it < G::ITER; ++it) {
+        const int v = tid + it * 256;
+        const int p = v / G::VPP, part = v % G::VPP;
+        const int py = p / G::HCOLS, px = p - py * G::HCOLS;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (v < G::NV && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const size_t off = (((size_t)gy * W + gx) * cin_p + (size_t)c * G::CKC) * G::ESZ + part * 16;
+            val = *reinterpret_cast<const u32x4*>(inb + off);
+        }
+        regs[it] = val;
+    }
+}
+
+template <class G, int PREC>
+__device__ __forceinline__ void stage_store(const u32x4 (&regs)[G::ITER], unsigned char* smem, int tid) {
+#pragma unroll
+    for (int it = 0; it < G::ITER; ++it) {
+        const int v = tid + it * 256;
+        if (v < G::NV) {
+            const int p = v / G::VPP, part = v % G::VPP;
+            if constexpr (PREC == P_BF16X3) {
+                const f32x4 f = __builtin_bit_cast(f32x4, regs[it]);
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hi[e] = (__bf16)f[e];
+                    lo[e] = (__bf16)(f[e] - (float)hi[e]);
+                }
+                *reinterpret_cast<u32x2*>(smem + p * G::PS + part * 8) = __builtin_bit_cast(u32x2, hi);
+                *reinterpret_cast<u32x2*>(smem + G::TILE_BYTES + p * G::PS + part * 8) = __builtin_bit_cast(u32x2, lo);
+            } else {
+                *reinterpret_cast<u32x4*>(smem + p * G::PS + part * 16) = regs[it];
+            }
+        }
+    }
+}
+
+// A fragments of one k-step: pixel (row, r + column shift) of the halo tile, 16 B at 32*s + 16*h
+template <class G, int MODE>
+__device__ __forceinline__ void load_a(u32x4 (&af)[G::MT][G::AV], const unsigned char* smem, int tap, int s,
+                                       int wave, int r, int h) {
+    const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+    for (int m = 0; m < G::MT; ++m) {
+        int hy, hx;
+        if constexpr (MODE == M_CONV) {
+            hy = 2 * wave + m + ky;
+            hx = r + kx;
+        } else {   // out[2i+ky] += in[i] w[ky]: ky = 2 reads the pixel above / left
+            hy = wave + 1 - (ky >> 1);
+            hx = r + 1 - (kx >> 1);
+        }
+        const int aoff = (hy * G::HCOLS + hx) * G::PS + 32 * s + 16 * h;
+#pragma unroll
+        for (int q = 0; q < G::AV; ++q) af[m][q] = *reinterpret_cast<const u32x4*>(smem + q * G::TILE_BYTES + aoff);
+    }
+}
+
+template <class G>
+__device__ __forceinline__ void load_b(u32x4 (&bf)[G::STEPV / 64], const u32x4* wbase, int gstep, int last_step) {
+    const int st = gstep < last_step ? gstep : last_step;   // clamp: the ring reads past the last step harmlessly
+    const u32x4* p = wbase + (size_t)st * G::STEPV;
+#pragma unroll
+    for (int i = 0; i < G::STEPV / 64; ++i) bf[i] = p[i * 64];
+}
+
+// one pass (= all taps of one output phase) over the staged chunk
+template <class G, int PREC, int MODE, int NT, int STEPS, int PASS>
+__device__ __forceinline__ void run_segment(f32x16 (&acc)[G::MT][NT], u32x4 (&ring)[G::R][G::STEPV / 64],
+                                            const unsigned char* smem, const u32x4* wbase, int gstep0, int last_step,
+                                            int wave, int r, int h) {
+    constexpr int NTAPS = pass_ntaps(MODE, PASS);
+    constexpr int NSEG = NTAPS * STEPS;
+    static_assert(NSEG % G::R == 0, "ring size must divide the segment length");
+    u32x4 af[2][G::MT][G::AV];
+    load_a<G, MODE>(af[0], smem, pass_tap(MODE, PASS, 0), 0, wave, r, h);
+#pragma unroll
+    for (int i = 0; i < NSEG; ++i) {
+        load_b<G>(ring[(i + G::PF) % G::R], wbase, gstep0 + i + G::PF, last_step);
+        if (i + 1 < NSEG)
+            load_a<G, MODE>(af[(i + 1) & 1], smem, pass_tap(MODE, PASS, (i + 1) / STEPS), (i + 1) % STEPS, wave, r, h);
+        const u32x4(&bf)[G::STEPV / 64] = ring[i % G::R];
+#pragma unroll
+        for (int m = 0; m < G::MT; ++m) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                if constexpr (PREC == P_BF16X3) {
+                    mma<PREC>(acc[m][n], af[i & 1][m][1], bf[n * 2 + 0]);   // lo * hi
+                    mma<PREC>(acc[m][n], af[i & 1][m][0], bf[n * 2 + 1]);   // hi * lo
+                    mma<PREC>(acc[m][n], af[i & 1][m][0], bf[n * 2 + 0]);   // hi * hi
+                } else {
+                    mma<PREC>(acc[m][n], af[i & 1][m][0], bf[n]);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <class G, int MODE, int NT>
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[G::MT][NT], const ConvArgs& a, int pass, int b, int y0,
+                                         int x0, int wave, int r, int h) {
+    const int H = a.H, W = a.W;
+    const int OW = MODE == M_CONV ? W : 2 * W;
+    const int OH = MODE == M_CONV ? H : 2 * H;
+#pragma unroll
+    for (int m = 0; m < G::MT; ++m) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = (blockIdx.y * NT + n) * 32 + r;
+            const float bias = a.bias[co];
+            const bool cok = co < a.cout_store;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int px = (i & 3) + 8 * (i >> 2) + 4 * h;
+                int iy, ix, oy, ox;
+                if constexpr (MODE == M_CONV) {
+                    iy = y0 + 2 * wave + m;
+                    ix = x0 + px;
+                    oy = iy;
+                    ox = ix;
+                } else {
+                    iy = y0 + wave;
+                    ix = x0 + px;
+                    oy = 2 * iy + (pass >> 1);
+                    ox = 2 * ix + (pass & 1);
+                }
+                if (cok && iy < H && ix < W) {
+                    const size_t opix = ((size_t)b * OH + oy) * OW + ox;
+                    float v = apply_act(acc[m][n][i] + bias, a.act);
+                    if (a.out_f32) {
+                        if (a.res) v += reinterpret_cast<const float*>(a.res)[opix * a.res_cs + co];
+                        reinterpret_cast<float*>(a.out)[opix * a.out_cs + co] = v;
+                    } else {
+                        if (a.res) v += (float)reinterpret_cast<const __bf16*>(a.res)[opix * a.res_cs + co];
+                        reinterpret_cast<__bf16*>(a.out)[opix * a.out_cs + co] = (__bf16)v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <class G, int NT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[G::MT][NT]) {
+#pragma unroll
+    for (int m = 0; m < G::MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+}
+
+template <int PREC, int MODE, int NT, int STEPS>
+__global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
+    using G = Geo<PREC, MODE, NT, STEPS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -82,151 +272,66 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
     tile /= a.tiles_x;
     const int tyi = tile % a.tiles_y;
     const int b = tile / a.tiles_y;
-    const int x0 = txi * TW, y0 = tyi * TH;
+    const int x0 = txi * TW, y0 = tyi * G::TH;
     const int H = a.H, W = a.W;
 
-    f32x16 acc[NPH][MT][NT];
-#pragma unroll
-    for (int p = 0; p < NPH; ++p)
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[p][m][n][i] = 0.f;
+    const u32x4* wbase = reinterpret_cast<const u32x4*>(a.wpack) + (size_t)blockIdx.y * a.wstride_cb + lane;
+    const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * H * W * a.cin_p * G::ESZ;
+    const int last_step = a.wstride_cb / G::STEPV - 1;
 
-    const u32x4* wp = reinterpret_cast<const u32x4*>(a.wpack) + (size_t)blockIdx.y * a.wstride_cb + lane;
-    const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * H * W * a.cin_p * ESZ;
+    // weight ring prologue: steps 0 .. PF-1
+    u32x4 ring[G::R][G::STEPV / 64];
+#pragma unroll
+    for (int i = 0; i < G::PF; ++i) load_b<G>(ring[i], wbase, i, last_step);
 
-    for (int c = 0; c < a.nchunk; ++c) {
-        // ---- stage the halo tile of chunk c: global -> registers -> LDS ----
-        u32x4 regs[ITER];
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int v = tid + it * 256;
-            const int p = v / VPP, part = v % VPP;
-            const int py = p / HALO_W, px = p - py * HALO_W;
-            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if (v < NV && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const size_t off = ((size_t)gy * W + gx) * a.cin_p * ESZ + (size_t)c * CKC * ESZ + part * 16;
-                val = *reinterpret_cast<const u32x4*>(inb + off);
-            }
-            regs[it] = val;
-        }
-        if (c) __syncthreads();   // every wave is done reading the previous chunk
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int v = tid + it * 256;
-            if (v < NV) {
-                const int p = v / VPP, part = v % VPP;
-                if constexpr (PREC == P_BF16X3) {
-                    const f32x4 f = __builtin_bit_cast(f32x4, regs[it]);
-                    bf16x4 hi, lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        hi[e] = (__bf16)f[e];
-                        lo[e] = (__bf16)(f[e] - (float)hi[e]);
-                    }
-                    *reinterpret_cast<u32x2*>(smem + p * PS + part * 8) = __builtin_bit_cast(u32x2, hi);
-                    *reinterpret_cast<u32x2*>(smem + TILE_BYTES + p * PS + part * 8) = __builtin_bit_cast(u32x2, lo);
-                } else {
-                    *reinterpret_cast<u32x4*>(smem + p * PS + part * 16) = regs[it];
-                }
+    u32x4 regs[G::ITER];
+    stage_load<G, PREC>(regs, inb, 0, a.cin_p, y0, x0, H, W, tid);
+    stage_store<G, PREC>(regs, smem, tid);
+    __syncthreads();
+
+    f32x16 acc[G::MT][NT];
+    if constexpr (MODE == M_CONV) {
+        zero_acc<G, NT>(acc);
+        constexpr int NSEG = 9 * STEPS;
+        for (int c = 0; c < a.nchunk; ++c) {
+            const bool more = c + 1 < a.nchunk;
+            if (more) stage_load<G, PREC>(regs, inb, c + 1, a.cin_p, y0, x0, H, W, tid);   // lands during the MFMAs
+            run_segment<G, PREC, MODE, NT, STEPS, 0>(acc, ring, smem, wbase, c * NSEG, last_step, wave, r, h);
+            if (more) {
+                __syncthreads();   // every wave is done reading chunk c
+                stage_store<G, PREC>(regs, smem, tid);
+                __syncthreads();
             }
         }
-        __syncthreads();
-
-        // ---- 9 taps x STEPS k-steps of MFMAs ----
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
-            const int ph = MODE == M_CONV ? 0 : ((ky & 1) * 2 + (kx & 1));
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                u32x4 bf[NT][BV];
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int q = 0; q < BV; ++q)
-                        bf[n][q] = wp[(size_t)((((tap * STEPS + s) * NT + n) * BV + q) * 64)];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    int hy, hx;
-                    if constexpr (MODE == M_CONV) {
-                        hy = 2 * wave + m + ky;
-                        hx = r + kx;
-                    } else {   // out[2i+ky] += in[i] w[ky]: ky = 2 reads the pixel above / left
-                        hy = wave + 1 - (ky >> 1);
-                        hx = r + 1 - (kx >> 1);
-                    }
-                    const int aoff = (hy * HALO_W + hx) * PS + 32 * s + 16 * h;
-                    const u32x4 af = *reinterpret_cast<const u32x4*>(smem + aoff);
-                    if constexpr (PREC == P_BF16X3) {
-                        const u32x4 al = *reinterpret_cast<const u32x4*>(smem + TILE_BYTES + aoff);
-#pragma unroll
-                        for (int n = 0; n < NT; ++n) {
-                            mma<PREC>(acc[ph][m][n], al, bf[n][0]);   // lo * hi
-                            mma<PREC>(acc[ph][m][n], af, bf[n][1]);   // hi * lo
-                            mma<PREC>(acc[ph][m][n], af, bf[n][0]);   // hi * hi
-                        }
-                    } else {
-#pragma unroll
-                        for (int n = 0; n < NT; ++n) mma<PREC>(acc[ph][m][n], af, bf[n][0]);
-                    }
-                }
-            }
-        }
-        wp += 9 * STEPS * NT * BV * 64;
-    }
-
-    // ---- epilogue: bias, activation, residual, store ----
-    const int OW = MODE == M_CONV ? W : 2 * W;
-    const int OH = MODE == M_CONV ? H : 2 * H;
-#pragma unroll
-    for (int p = 0; p < NPH; ++p) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int co = (blockIdx.y * NT + n) * 32 + r;
-                const float bias = a.bias[co];
-                const bool cok = co < a.cout_store;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int px = (i & 3) + 8 * (i >> 2) + 4 * h;
-                    int iy, ix, oy, ox;
-                    if constexpr (MODE == M_CONV) {
-                        iy = y0 + 2 * wave + m;
-                        ix = x0 + px;
-                        oy = iy;
-                        ox = ix;
-                    } else {
-                        iy = y0 + wave;
-                        ix = x0 + px;
-                        oy = 2 * iy + (p >> 1);
-                        ox = 2 * ix + (p & 1);
-                    }
-                    if (cok && iy < H && ix < W) {
-                        const size_t opix = ((size_t)b * OH + oy) * OW + ox;
-                        float v = apply_act(acc[p][m][n][i] + bias, a.act);
-                        if (a.out_f32) {
-                            if (a.res) v += reinterpret_cast<const float*>(a.res)[opix * a.res_cs + co];
-                            reinterpret_cast<float*>(a.out)[opix * a.out_cs + co] = v;
-                        } else {
-                            if (a.res) v += (float)reinterpret_cast<const __bf16*>(a.res)[opix * a.res_cs + co];
-                            reinterpret_cast<__bf16*>(a.out)[opix * a.out_cs + co] = (__bf16)v;
-                        }
-                    }
-                }
-            }
-        }
+        epilogue<G, MODE, NT>(acc, a, 0, b, y0, x0, wave, r, h);
+    } else {
+        // pass-major, chunk-minor; with one chunk (every layer of this network) the tile is staged once
+        int gstep = 0;
+        auto restage = [&](int c) {
+            __syncthreads();
+            stage_load<G, PREC>(regs, inb, c, a.cin_p, y0, x0, H, W, tid);
+            stage_store<G, PREC>(regs, smem, tid);
+            __syncthreads();
+        };
+#define SR_PASS(P)                                                                                              \
+        zero_acc<G, NT>(acc);                                                                                   \
+        for (int c = 0; c < a.nchunk; ++c) {                                                                    \
+            if (a.nchunk > 1 && (P > 0 || c > 0)) restage(c);                                                   \
+            run_segment<G, PREC, MODE, NT, STEPS, P>(acc, ring, smem, wbase, gstep, last_step, wave, r, h);     \
+            gstep += pass_ntaps(MODE, P) * STEPS;                                                               \
+        }                                                                                                       \
+        epilogue<G, MODE, NT>(acc, a, P, b, y0, x0, wave, r, h);
+        SR_PASS(0)
+        SR_PASS(1)
+        SR_PASS(2)
+        SR_PASS(3)
+#undef SR_PASS
     }
 }
 
 size_t conv_lds_bytes(int prec, int mode, int steps) {
-    const int th = mode == M_CONV ? 8 : 4;
-    const size_t tile = (size_t)(th + 2) * HALO_W * (32 * steps + 16);
+    const int th = mode == M_CONV ? 8 : 4, hb = mode == M_CONV ? 1 : 0;
+    const size_t tile = (size_t)(th + 1 + hb) * (TW + 1 + hb) * (32 * steps + 16);
     return prec == P_BF16X3 ? 2 * tile : tile;
 }
 
@@ -234,17 +339,27 @@ template <int PREC, int MODE, int NT, int STEPS>
 static hipError_t launch_one(const ConvArgs& a, int ncb, hipStream_t s) {
     const dim3 grid(a.tiles_x * a.tiles_y * a.B, ncb);
     const size_t lds = conv_lds_bytes(PREC, MODE, STEPS);
+    static bool attr_done = false;
+    if (lds > 64 * 1024 && !attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<PREC, MODE, NT, STEPS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
     hipLaunchKernelGGL((conv3x3_kernel<PREC, MODE, NT, STEPS>), grid, dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
 template <int PREC, int MODE, int NT>
 static hipError_t launch_steps(int steps, const ConvArgs& a, int ncb, hipStream_t s) {
-    constexpr int MAXS = prec_maxsteps(PREC);
+    constexpr int MAXS = prec_maxsteps(PREC, MODE);
     if (steps == 1) return launch_one<PREC, MODE, NT, 1>(a, ncb, s);
     if (steps == 2) return launch_one<PREC, MODE, NT, 2>(a, ncb, s);
-    if constexpr (MAXS == 4) {
+    if constexpr (MAXS >= 4) {
         if (steps == 4) return launch_one<PREC, MODE, NT, 4>(a, ncb, s);
+    }
+    if constexpr (MAXS >= 8) {
+        if (steps == 8) return launch_one<PREC, MODE, NT, 8>(a, ncb, s);
     }
     return hipErrorInvalidValue;
 }
@@ -254,9 +369,8 @@ static hipError_t launch_prec(int mode, int nt, int steps, const ConvArgs& a, in
     if (mode == M_CONV) {
         if (nt == 1) return launch_steps<PREC, M_CONV, 1>(steps, a, ncb, s);
         if (nt == 2) return launch_steps<PREC, M_CONV, 2>(steps, a, ncb, s);
-    } else {
-        if (nt == 1) return launch_steps<PREC, M_CONVT, 1>(steps, a, ncb, s);
-        if (nt == 2) return launch_steps<PREC, M_CONVT, 2>(steps, a, ncb, s);
+    } else if (nt == 2) {
+        return launch_steps<PREC, M_CONVT, 2>(steps, a, ncb, s);
     }
     return hipErrorInvalidValue;
 }

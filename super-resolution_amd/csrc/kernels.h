@@ -14,7 +14,6 @@ enum ConvMode { M_CONV = 0, M_CONVT = 1 };
 // TH x 32 pixel tile of NT*32 output channels; the (TH+2) x 34 halo tile of one
 // input-channel chunk is staged in LDS, pixel-major, 16 B of padding per pixel.
 constexpr int TW = 32;
-constexpr int HALO_W = TW + 2;
 
 struct ConvArgs {
     const void* in;        // [B,H,W,cin_p] activations (float or bf16)
@@ -36,7 +35,11 @@ struct ConvArgs {
 
 // steps per chunk / chunk geometry, shared by the packer and the kernel
 __host__ __device__ constexpr int prec_ks(int prec) { return prec == P_FP32 ? 8 : 16; }      // channels per k-step
-__host__ __device__ constexpr int prec_maxsteps(int prec) { return prec == P_BF16X3 ? 2 : 4; }
+// conv: chunks of at most 128 payload bytes per pixel (x3: 64 B in each of the hi and lo tiles);
+// transposed conv: all 64 input channels of this network's layers in ONE chunk
+__host__ __device__ constexpr int prec_maxsteps(int prec, int mode) {
+    return mode == M_CONV ? (prec == P_BF16X3 ? 2 : 4) : (prec == P_FP32 ? 8 : 4);
+}
 
 // host-side launchers (conv_mfma.hip)
 hipError_t launch_conv(int prec, int mode, int nt, int steps, const ConvArgs& a, int ncb, hipStream_t s);

@@ -102,11 +102,18 @@ int fail(sr_ctx* c, int code, const char* fmt, ...) {
     } while (0)
 
 // ---------------------------------------------------------------- weight packing
-// Order inside one output-channel block: [chunk][tap][step][n block][hi,lo][lane] x 16 B,
+// Order inside one output-channel block: [pass][chunk][tap of pass][step][n block][hi,lo][lane] x 16 B
+// (conv: one pass of 9 taps; transposed conv: the four output phases of conv_mfma.hip's pass_tap),
 // lane (j = lane & 31, hh = lane >> 5) holding input channels
 //   chunk*CKC + step*KS + (KS/2)*hh + e   (e < KS/2)   of output channel cb*NT*32 + n*32 + j,
 // i.e. exactly the B fragment of v_mfma_f32_32x32x2_f32 (4 successive k-pairs per vector)
-// or v_mfma_f32_32x32x16_bf16 that conv3x3_kernel consumes.
+// or v_mfma_f32_32x32x16_bf16 that conv3x3_kernel consumes, in the order it consumes them.
+int pass_ntaps_h(int mode, int pass) { return mode == M_CONV ? 9 : (pass == 0 ? 4 : (pass == 3 ? 1 : 2)); }
+int pass_tap_h(int mode, int pass, int t) {
+    static const int T[4][4] = {{0, 2, 6, 8}, {1, 7, 0, 0}, {3, 5, 0, 0}, {4, 0, 0, 0}};
+    return mode == M_CONV ? t : T[pass][t];
+}
+
 void plan_layer(ConvLayer& L, int prec, int mode, int cin, int cout) {
     L.mode = mode;
     L.cin = cin;
@@ -114,7 +121,7 @@ void plan_layer(ConvLayer& L, int prec, int mode, int cin, int cout) {
     L.cin_p = round_up(cin, 16);
     const int ks = prec_ks(prec);
     const int total_steps = L.cin_p / ks;
-    int steps = prec_maxsteps(prec);
+    int steps = prec_maxsteps(prec, mode);
     while (total_steps % steps) steps >>= 1;
     L.steps = steps;
     L.nchunk = total_steps / steps;
@@ -128,37 +135,42 @@ std::vector<uint8_t> pack_weights(const ConvLayer& L, int prec, const float* w) 
     const int ks = prec_ks(prec), half = ks / 2;
     const int bv = prec == P_BF16X3 ? 2 : 1;
     const int ckc = L.steps * ks;
+    const int npass = L.mode == M_CONV ? 1 : 4;
     std::vector<uint8_t> out((size_t)L.ncb * L.wstride_cb * 16, 0);
     auto W = [&](int ky, int kx, int ci, int co) -> float {
         if (ci >= L.cin || co >= L.cout) return 0.f;
         if (L.mode == M_CONV) return w[((size_t)(ky * 3 + kx) * L.cin + ci) * L.cout + co];
         return w[((size_t)(ky * 3 + kx) * L.cout + co) * L.cin + ci];   // Conv2DTranspose: (kh,kw,out,in)
     };
-    for (int cb = 0; cb < L.ncb; ++cb)
-        for (int c = 0; c < L.nchunk; ++c)
-            for (int tap = 0; tap < 9; ++tap)
-                for (int s = 0; s < L.steps; ++s)
-                    for (int n = 0; n < L.nt; ++n)
-                        for (int lane = 0; lane < 64; ++lane) {
-                            const int j = lane & 31, hh = lane >> 5;
-                            const int co = (cb * L.nt + n) * 32 + j;
-                            const size_t vbase = (size_t)cb * L.wstride_cb +
-                                                 ((size_t)((c * 9 + tap) * L.steps + s) * L.nt + n) * bv * 64;
-                            for (int e = 0; e < half; ++e) {
-                                const int ci = c * ckc + s * ks + half * hh + e;
-                                const float v = W(tap / 3, tap % 3, ci, co);
-                                if (prec == P_FP32) {
-                                    memcpy(&out[(vbase + lane) * 16 + e * 4], &v, 4);
-                                } else {
-                                    const uint16_t hi = f2bf(v);
-                                    memcpy(&out[(vbase + lane) * 16 + e * 2], &hi, 2);
-                                    if (prec == P_BF16X3) {
-                                        const uint16_t lo = f2bf(v - bf2f(hi));
-                                        memcpy(&out[(vbase + 64 + lane) * 16 + e * 2], &lo, 2);
+    for (int cb = 0; cb < L.ncb; ++cb) {
+        size_t gstep = 0;   // k-step counter in kernel consumption order
+        for (int pass = 0; pass < npass; ++pass)
+            for (int c = 0; c < L.nchunk; ++c)
+                for (int t = 0; t < pass_ntaps_h(L.mode, pass); ++t)
+                    for (int s = 0; s < L.steps; ++s, ++gstep) {
+                        const int tap = pass_tap_h(L.mode, pass, t);
+                        for (int n = 0; n < L.nt; ++n)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int j = lane & 31, hh = lane >> 5;
+                                const int co = (cb * L.nt + n) * 32 + j;
+                                const size_t vbase = (size_t)cb * L.wstride_cb + (gstep * L.nt + n) * bv * 64;
+                                for (int e = 0; e < half; ++e) {
+                                    const int ci = c * ckc + s * ks + half * hh + e;
+                                    const float v = W(tap / 3, tap % 3, ci, co);
+                                    if (prec == P_FP32) {
+                                        memcpy(&out[(vbase + lane) * 16 + e * 4], &v, 4);
+                                    } else {
+                                        const uint16_t hi = f2bf(v);
+                                        memcpy(&out[(vbase + lane) * 16 + e * 2], &hi, 2);
+                                        if (prec == P_BF16X3) {
+                                            const uint16_t lo = f2bf(v - bf2f(hi));
+                                            memcpy(&out[(vbase + 64 + lane) * 16 + e * 2], &lo, 2);
+                                        }
                                     }
                                 }
                             }
-                        }
+                    }
+    }
     return out;
 }
 
