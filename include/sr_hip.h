@@ -146,6 +146,12 @@ int sr_op_warp(int device, int B, int H, int W, int C, const float* img, const f
 /* tf.space_to_depth(x, bs): reference layers.py:109.  out (B,H/bs,W/bs,bs*bs*C). */
 int sr_op_space_to_depth(int device, int B, int H, int W, int C, int bs, const float* x, float* out);
 
+/* Measurement utility (no reference counterpart): times `iters` back-to-back launches
+ * of one 3x3 conv (or stride-2 transposed conv) layer on device-resident random data
+ * with HIP events; used by tools/conv_bench.py to iterate on the MFMA kernels. */
+int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, int Cin, int Cout,
+                  int residual, int iters, float* ms_per_launch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,9 +14,9 @@
 //   ring that runs PF k-steps ahead of the MFMAs (the stream is contiguous over
 //   passes, chunks, taps and steps, so the ring never drains inside a tile).
 //   The next chunk's halo tile is fetched into registers while the current
-//   chunk computes.  D layout of v_mfma_*_32x32: column (lane & 31) = output
-//   channel, the 16 accumulator registers = pixels, so every store instruction
-//   writes 32 consecutive channels of one pixel per half-wave.
+//   chunk computes.  The weights are the MFMA's A operand and the pixels its B
+//   operand: D then has the pixel on the lane (lane & 31) and 4 consecutive output
+//   channels per register quad, so the epilogue stores 16 B per lane.
 //
 //   M_CONV : 8-row tiles, one pass over 9 taps, chunks of 32*STEPS payload bytes.
 //   M_CONVT: out[2i+ky, 2j+kx] += in[i,j] w[ky,kx]  =>  four output phases
@@ -191,11 +191,11 @@ __device__ __forceinline__ void run_segment(f32x16 (&acc)[G::MT][NT], u32x4 (&ri
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 if constexpr (PREC == P_BF16X3) {
-                    mma<PREC>(acc[m][n], af[i & 1][m][1], bf[n * 2 + 0]);   // lo * hi
-                    mma<PREC>(acc[m][n], af[i & 1][m][0], bf[n * 2 + 1]);   // hi * lo
-                    mma<PREC>(acc[m][n], af[i & 1][m][0], bf[n * 2 + 0]);   // hi * hi
+                    mma<PREC>(acc[m][n], bf[n * 2 + 0], af[i & 1][m][1]);   // w_hi * x_lo
+                    mma<PREC>(acc[m][n], bf[n * 2 + 1], af[i & 1][m][0]);   // w_lo * x_hi
+                    mma<PREC>(acc[m][n], bf[n * 2 + 0], af[i & 1][m][0]);   // w_hi * x_hi
                 } else {
-                    mma<PREC>(acc[m][n], af[i & 1][m][0], bf[n]);
+                    mma<PREC>(acc[m][n], bf[n], af[i & 1][m][0]);
                 }
             }
         }
@@ -203,48 +203,97 @@ __device__ __forceinline__ void run_segment(f32x16 (&acc)[G::MT][NT], u32x4 (&ri
     }
 }
 
-template <class G, int MODE, int NT>
-__device__ __forceinline__ void epilogue(const f32x16 (&acc)[G::MT][NT], const ConvArgs& a, int pass, int b, int y0,
-                                         int x0, int wave, int r, int h) {
+// tanh(x) = 1 - 2 / (exp(2x) + 1): absolute error ~1e-7, saturates correctly at +-inf
+__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f / (__expf(2.f * x) + 1.f); }
+
+// The weights are the MFMA's A operand and the pixels its B operand, so D has the pixel on the
+// lane (lane & 31) and 4 consecutive output channels n*32 + 8g + 4h + (0..3) in registers
+// 4g..4g+3: a lane stores 16 B (8 B for bf16) per g, and a 3-channel output row is one lane's.
+template <class G, int MODE, int NT, typename OT>
+__device__ __forceinline__ void epilogue_t(const f32x16 (&acc)[G::MT][NT], const ConvArgs& a, int pass, int b, int y0,
+                                           int x0, int wave, int r, int h) {
     const int H = a.H, W = a.W;
     const int OW = MODE == M_CONV ? W : 2 * W;
     const int OH = MODE == M_CONV ? H : 2 * H;
+    const int act = a.act;
+    const float slope = (act == A_RELU || act == A_CLIP01) ? 0.f : (act == A_LRELU ? 0.2f : 1.f);
+    const float hi = act == A_CLIP01 ? 1.f : INFINITY;
+    const int ix = x0 + r;
+    const bool vec = (a.out_cs % 4 == 0) && (a.cout_store % 4 == 0) && (!a.res || a.res_cs % 4 == 0) && act != A_TANH;
+    OT* outp = reinterpret_cast<OT*>(a.out);
+    const OT* resp = reinterpret_cast<const OT*>(a.res);
 #pragma unroll
     for (int m = 0; m < G::MT; ++m) {
+        int iy, oy, ox;
+        if constexpr (MODE == M_CONV) {
+            iy = y0 + 2 * wave + m;
+            oy = iy;
+            ox = ix;
+        } else {
+            iy = y0 + wave;
+            oy = 2 * iy + (pass >> 1);
+            ox = 2 * ix + (pass & 1);
+        }
+        const bool pok = iy < H && ix < W;
+        const size_t opix = ((size_t)b * OH + oy) * OW + ox;
+        OT* op = outp + opix * a.out_cs;
+        const OT* rp = resp ? resp + opix * a.res_cs : nullptr;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const int co = (blockIdx.y * NT + n) * 32 + r;
-            const float bias = a.bias[co];
-            const bool cok = co < a.cout_store;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int px = (i & 3) + 8 * (i >> 2) + 4 * h;
-                int iy, ix, oy, ox;
-                if constexpr (MODE == M_CONV) {
-                    iy = y0 + 2 * wave + m;
-                    ix = x0 + px;
-                    oy = iy;
-                    ox = ix;
-                } else {
-                    iy = y0 + wave;
-                    ix = x0 + px;
-                    oy = 2 * iy + (pass >> 1);
-                    ox = 2 * ix + (pass & 1);
+            for (int g = 0; g < 4; ++g) {
+                const int co = (blockIdx.y * NT + n) * 32 + 8 * g + 4 * h;
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + co);
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = acc[m][n][4 * g + j] + bias[j];
+                    t = t > 0.f ? t : t * slope;
+                    v[j] = fminf(t, hi);
                 }
-                if (cok && iy < H && ix < W) {
-                    const size_t opix = ((size_t)b * OH + oy) * OW + ox;
-                    float v = apply_act(acc[m][n][i] + bias, a.act);
-                    if (a.out_f32) {
-                        if (a.res) v += reinterpret_cast<const float*>(a.res)[opix * a.res_cs + co];
-                        reinterpret_cast<float*>(a.out)[opix * a.out_cs + co] = v;
-                    } else {
-                        if (a.res) v += (float)reinterpret_cast<const __bf16*>(a.res)[opix * a.res_cs + co];
-                        reinterpret_cast<__bf16*>(a.out)[opix * a.out_cs + co] = (__bf16)v;
+                if (vec) {
+                    if (pok && co < a.cout_store) {
+                        if constexpr (sizeof(OT) == 4) {
+                            if (rp) {
+                                const f32x4 rr = *reinterpret_cast<const f32x4*>(rp + co);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] += rr[j];
+                            }
+                            f32x4 o = {v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<f32x4*>(op + co) = o;
+                        } else {
+                            if (rp) {
+                                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(rp + co);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] += (float)rr[j];
+                            }
+                            bf16x4 o;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
+                            *reinterpret_cast<bf16x4*>(op + co) = o;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (pok && co + j < a.cout_store) {
+                            float t = v[j];
+                            if (act == A_TANH) t = tanh_fast(t);
+                            if (rp) t += (float)rp[co + j];
+                            op[co + j] = (OT)t;
+                        }
                     }
                 }
             }
         }
     }
+}
+
+template <class G, int MODE, int NT>
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[G::MT][NT], const ConvArgs& a, int pass, int b, int y0,
+                                         int x0, int wave, int r, int h) {
+    if (a.out_f32) epilogue_t<G, MODE, NT, float>(acc, a, pass, b, y0, x0, wave, r, h);
+    else epilogue_t<G, MODE, NT, __bf16>(acc, a, pass, b, y0, x0, wave, r, h);
 }
 
 template <class G, int NT>

@@ -885,4 +885,52 @@ int sr_op_space_to_depth(int device, int B, int H, int W, int C, int bs, const f
     });
 }
 
+int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, int Cin, int Cout, int residual,
+                  int iters, float* ms_per_launch) {
+    int rc = op_prologue(device);
+    if (rc) return rc;
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || iters < 1 || !ms_per_launch)
+        return fail(nullptr, SR_ERR_ARG, "bad argument");
+    if (dtype < 0 || dtype > 2) return fail(nullptr, SR_ERR_ARG, "bad dtype");
+    const int mode = transposed ? M_CONVT : M_CONV;
+    ConvLayer L;
+    plan_layer(L, dtype, mode, Cin, Cout);
+    struct Guard { ConvLayer& l; ~Guard() { free_layer(l); } } guard{L};
+    std::vector<float> w((size_t)9 * Cin * Cout), bias(Cout, 0.01f);
+    uint32_t st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 65536.0f - 0.5f; };
+    for (auto& v : w) v = rnd() * 0.1f;
+    if ((rc = upload_layer(nullptr, L, dtype, w.data(), bias.data()))) return rc;
+    DevBufs d;
+    const size_t npix = (size_t)B * H * W, opix = mode == M_CONV ? npix : 4 * npix;
+    const size_t es = dtype == SR_BF16 ? 2 : 4;
+    const int cout_p = round_up(Cout, 16);
+    std::vector<float> x(npix * Cin);
+    for (auto& v : x) v = rnd();
+    float* d_x = (float*)d.get(npix * Cin * 4);
+    void* d_xp = d.get(npix * L.cin_p * es);
+    void* d_out = d.get(opix * cout_p * es);
+    if (!d_x || !d_xp || !d_out) return fail(nullptr, SR_ERR_HIP, "hipMalloc failed");
+    HIPCHK(nullptr, hipMemcpy(d_x, x.data(), npix * Cin * 4, hipMemcpyHostToDevice));
+    LAUNCHCHK(nullptr, "pad_channels", launch_pad_channels(d_x, d_xp, dtype == SR_BF16, (long)npix, Cin, L.cin_p, nullptr));
+    HIPCHK(nullptr, hipMemset(d_out, 0, opix * cout_p * es));
+    const ConvIO io{d_xp, H, W, d_out, cout_p, Cout, dtype == SR_BF16 ? 0 : 1, residual ? d_out : nullptr, cout_p, A_RELU};
+    for (int i = 0; i < 3; ++i)
+        if ((rc = run_conv(nullptr, dtype, nullptr, L, B, io, "bench_conv"))) return rc;
+    hipEvent_t e0, e1;
+    HIPCHK(nullptr, hipEventCreate(&e0));
+    HIPCHK(nullptr, hipEventCreate(&e1));
+    HIPCHK(nullptr, hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i)
+        if ((rc = run_conv(nullptr, dtype, nullptr, L, B, io, "bench_conv"))) return rc;
+    HIPCHK(nullptr, hipEventRecord(e1, nullptr));
+    HIPCHK(nullptr, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(nullptr, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_launch = ms / iters;
+    return SR_OK;
+}
+
 }  // extern "C"

@@ -52,6 +52,7 @@ SIGNATURES = {
     "sr_op_resize_bilinear": (C.c_int, [C.c_int] * 6 + [_vp, _vp]),
     "sr_op_warp": (C.c_int, [C.c_int] * 5 + [_vp, _vp, _vp]),
     "sr_op_space_to_depth": (C.c_int, [C.c_int] * 6 + [_vp, _vp]),
+    "sr_bench_conv": (C.c_int, [C.c_int] * 10 + [C.POINTER(C.c_float)]),
 }
 
 _lib = None
@@ -297,3 +298,11 @@ def space_to_depth(x, bs=4, device=0):
     out = np.empty((B, H // bs, W // bs, bs * bs * Cc), np.float32)
     _check(lib().sr_op_space_to_depth(device, B, H, W, Cc, bs, _ptr(x), _ptr(out)))
     return out
+
+
+def bench_conv(B, H, W, Cin, Cout, dtype="bf16x3", transposed=False, residual=False, iters=20, device=0):
+    """Milliseconds per launch of one conv layer on device-resident random data."""
+    ms = C.c_float()
+    _check(lib().sr_bench_conv(device, DTYPES[dtype], int(transposed), B, H, W, Cin, Cout, int(residual), iters,
+                               C.byref(ms)))
+    return ms.value
