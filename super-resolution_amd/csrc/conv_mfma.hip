@@ -29,6 +29,8 @@
 //                      MFMAs per product (lo*hi + hi*lo + hi*hi), fp32 accumulate.
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace sr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -48,6 +50,12 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+__device__ __forceinline__ void keep_alive(const f32x16& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(v));
+#endif
+}
+
 template <int PREC>
 __device__ __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b) {
     if constexpr (PREC == P_FP32) {
@@ -59,6 +67,13 @@ __device__ __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
                                                       __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     }
+}
+
+// PL (pixel-on-lane): weights are the A operand, pixels the B operand; otherwise the reverse
+template <int PREC, bool PL>
+__device__ __forceinline__ void mma_wx(f32x16& acc, const u32x4& w, const u32x4& x) {
+    if constexpr (PL) mma<PREC>(acc, w, x);
+    else mma<PREC>(acc, x, w);
 }
 
 template <int PREC, int MODE, int NT, int STEPS>
@@ -191,11 +206,11 @@ __device__ __forceinline__ void run_segment(f32x16 (&acc)[G::MT][NT], u32x4 (&ri
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 if constexpr (PREC == P_BF16X3) {
-                    mma<PREC>(acc[m][n], bf[n * 2 + 0], af[i & 1][m][1]);   // w_hi * x_lo
-                    mma<PREC>(acc[m][n], bf[n * 2 + 1], af[i & 1][m][0]);   // w_lo * x_hi
-                    mma<PREC>(acc[m][n], bf[n * 2 + 0], af[i & 1][m][0]);   // w_hi * x_hi
+                    mma_wx<PREC, true>(acc[m][n], bf[n * 2 + 0], af[i & 1][m][1]);   // w_hi * x_lo
+                    mma_wx<PREC, true>(acc[m][n], bf[n * 2 + 1], af[i & 1][m][0]);   // w_lo * x_hi
+                    mma_wx<PREC, true>(acc[m][n], bf[n * 2 + 0], af[i & 1][m][0]);   // w_hi * x_hi
                 } else {
-                    mma<PREC>(acc[m][n], bf[n], af[i & 1][m][0]);
+                    mma_wx<PREC, true>(acc[m][n], bf[n], af[i & 1][m][0]);
                 }
             }
         }
@@ -289,11 +304,66 @@ __device__ __forceinline__ void epilogue_t(const f32x16 (&acc)[G::MT][NT], const
     }
 }
 
-template <class G, int MODE, int NT>
+// Channel-on-lane layout (pixels are the MFMA's A operand, weights its B operand): D has the output
+// channel on the lane (lane & 31) and 16 pixels (i&3) + 8(i>>2) + 4h in the registers, so one store
+// instruction writes two full 128-byte lines (32 consecutive fp32 channels of two pixels).
+template <class G, int MODE, int NT, typename OT>
+__device__ __forceinline__ void epilogue_cl(const f32x16 (&acc)[G::MT][NT], const ConvArgs& a, int pass, int b, int y0,
+                                            int x0, int wave, int r, int h) {
+    const int H = a.H, W = a.W;
+    const int OW = MODE == M_CONV ? W : 2 * W;
+    const int OH = MODE == M_CONV ? H : 2 * H;
+    const int act = a.act;
+    const float slope = (act == A_RELU || act == A_CLIP01) ? 0.f : (act == A_LRELU ? 0.2f : 1.f);
+    const float hi = act == A_CLIP01 ? 1.f : INFINITY;
+    constexpr int XS = MODE == M_CONV ? 1 : 2;   // output pixels per input pixel along x
+    OT* outp = reinterpret_cast<OT*>(a.out);
+    const OT* resp = reinterpret_cast<const OT*>(a.res);
+#pragma unroll
+    for (int m = 0; m < G::MT; ++m) {
+        int iy, oy;
+        if constexpr (MODE == M_CONV) {
+            iy = y0 + 2 * wave + m;
+            oy = iy;
+        } else {
+            iy = y0 + wave;
+            oy = 2 * iy + (pass >> 1);
+        }
+        const int ox0 = XS * (x0 + 4 * h) + (MODE == M_CONV ? 0 : (pass & 1));
+        const size_t opix = ((size_t)b * OH + oy) * OW + ox0;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = (blockIdx.y * NT + n) * 32 + r;
+            const float bias = a.bias[co];
+            const bool cok = co < a.cout_store && iy < H;
+            OT* op = outp + opix * a.out_cs + co;
+            const OT* rp = resp ? resp + opix * a.res_cs + co : nullptr;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int px = (i & 3) + 8 * (i >> 2);           // + 4h, folded into ox0
+                if (cok && x0 + 4 * h + px < W) {
+                    float t = acc[m][n][i] + bias;
+                    t = t > 0.f ? t : t * slope;
+                    t = fminf(t, hi);
+                    if (act == A_TANH) t = tanh_fast(t);
+                    if (rp) t += (float)rp[(size_t)(XS * px) * a.res_cs];
+                    op[(size_t)(XS * px) * a.out_cs] = (OT)t;
+                }
+            }
+        }
+    }
+}
+
+template <class G, int MODE, int NT, bool PL>
 __device__ __forceinline__ void epilogue(const f32x16 (&acc)[G::MT][NT], const ConvArgs& a, int pass, int b, int y0,
                                          int x0, int wave, int r, int h) {
-    if (a.out_f32) epilogue_t<G, MODE, NT, float>(acc, a, pass, b, y0, x0, wave, r, h);
-    else epilogue_t<G, MODE, NT, __bf16>(acc, a, pass, b, y0, x0, wave, r, h);
+    if constexpr (PL) {
+        if (a.out_f32) epilogue_t<G, MODE, NT, float>(acc, a, pass, b, y0, x0, wave, r, h);
+        else epilogue_t<G, MODE, NT, __bf16>(acc, a, pass, b, y0, x0, wave, r, h);
+    } else {
+        if (a.out_f32) epilogue_cl<G, MODE, NT, float>(acc, a, pass, b, y0, x0, wave, r, h);
+        else epilogue_cl<G, MODE, NT, __bf16>(acc, a, pass, b, y0, x0, wave, r, h);
+    }
 }
 
 template <class G, int NT>
@@ -352,7 +422,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
                 __syncthreads();
             }
         }
-        epilogue<G, MODE, NT>(acc, a, 0, b, y0, x0, wave, r, h);
+        epilogue<G, MODE, NT, true>(acc, a, 0, b, y0, x0, wave, r, h);
     } else {
         // pass-major, chunk-minor; with one chunk (every layer of this network) the tile is staged once
         int gstep = 0;
@@ -369,7 +439,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
             run_segment<G, PREC, MODE, NT, STEPS, P>(acc, ring, smem, wbase, gstep, last_step, wave, r, h);     \
             gstep += pass_ntaps(MODE, P) * STEPS;                                                               \
         }                                                                                                       \
-        epilogue<G, MODE, NT>(acc, a, P, b, y0, x0, wave, r, h);
+        epilogue<G, MODE, NT, true>(acc, a, P, b, y0, x0, wave, r, h);
         SR_PASS(0)
         SR_PASS(1)
         SR_PASS(2)
@@ -378,32 +448,318 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
     }
 }
 
-size_t conv_lds_bytes(int prec, int mode, int steps) {
-    const int th = mode == M_CONV ? 8 : 4, hb = mode == M_CONV ? 1 : 0;
-    const size_t tile = (size_t)(th + 1 + hb) * (TW + 1 + hb) * (32 * steps + 16);
-    return prec == P_BF16X3 ? 2 * tile : tile;
+// Epilogue through LDS (M_CONV, pixel-on-lane accumulators): each wave transposes its 64 pixels x
+// NT*32 channels through a private LDS scratch so that global stores (and residual loads) are 16 B
+// per lane AND contiguous across lanes: one instruction covers whole pixel rows, i.e. full 128-B lines.
+template <class G, int NT, typename OT>
+struct EpiLds {
+    static constexpr int RB = NT * 32 * (int)sizeof(OT);   // bytes of one pixel's channel row
+    static constexpr int ROW = RB + 16;                     // + pad: conflict-free 16-B column writes
+    static constexpr int LPR = RB / 16;                     // lanes per pixel row
+    static constexpr int RPI = 64 / LPR;                    // pixel rows per wave instruction
+    static constexpr int NIT = 64 / RPI;
+    static constexpr int WAVE_BYTES = 64 * ROW;
+};
+
+template <class G, int NT, typename OT>
+__device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[G::MT][NT], const ConvArgs& a, int b, int y0, int x0,
+                                             int wave, int lane, unsigned char* smem) {
+    using E = EpiLds<G, NT, OT>;
+    static_assert(G::MT == 2, "two 32-pixel rows per wave");
+    const int r = lane & 31, h = lane >> 5;
+    const int H = a.H, W = a.W;
+    const int act = a.act;
+    const float slope = (act == A_RELU || act == A_CLIP01) ? 0.f : (act == A_LRELU ? 0.2f : 1.f);
+    const float hi = act == A_CLIP01 ? 1.f : INFINITY;
+    unsigned char* sc = smem + wave * E::WAVE_BYTES;
+    const int cbase = blockIdx.y * NT * 32;
+    // row/column of this lane in the transposed phase
+    const int prow = lane / E::LPR, chunk = lane % E::LPR;
+    constexpr int EPV = 16 / (int)sizeof(OT);               // channels per 16-B vector
+    const int co = cbase + chunk * EPV;
+    const bool cok = co < a.cout_store;
+    OT* outp = reinterpret_cast<OT*>(a.out);
+    const OT* resp = reinterpret_cast<const OT*>(a.res);
+
+    // 1. bias + activation, column writes: lane = pixel r, 4 channels n*32 + 8g + 4h + (0..3) per store
+#pragma unroll
+    for (int m = 0; m < G::MT; ++m) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = n * 32 + 8 * g + 4 * h;
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + cbase + cl);
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = acc[m][n][4 * g + j] + bias[j];
+                    t = t > 0.f ? t : t * slope;
+                    v[j] = fminf(t, hi);
+                }
+                unsigned char* dst = sc + (m * 32 + r) * E::ROW + cl * (int)sizeof(OT);
+                if constexpr (sizeof(OT) == 4) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(dst) = o;
+                } else {
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
+                    *reinterpret_cast<bf16x4*>(dst) = o;
+                }
+            }
+        }
+    }
+    // 2. row reads (same wave: LDS ops of one wave execute in order), residual add, coalesced stores
+    const int iy0 = y0 + 2 * wave;
+    const int p0 = prow;                                     // pixel of iteration 0; iteration k adds k*RPI
+    const bool colok = cok;
+#pragma unroll
+    for (int k = 0; k < E::NIT; ++k) {
+        const int p = p0 + k * E::RPI;                       // 0..63: m = p >> 5, px = p & 31
+        const int iy = iy0 + (p >> 5), ix = x0 + (p & 31);
+        const bool ok = colok && iy < H && ix < W;
+        const size_t opix = ((size_t)b * H + iy) * W + ix;
+        u32x4 val = *reinterpret_cast<const u32x4*>(sc + p * E::ROW + chunk * 16);
+        if (ok) {
+            if (resp) {
+                const u32x4 rr = *reinterpret_cast<const u32x4*>(resp + opix * a.res_cs + co);
+                if constexpr (sizeof(OT) == 4) {
+                    f32x4 x = __builtin_bit_cast(f32x4, val), y = __builtin_bit_cast(f32x4, rr);
+                    x += y;
+                    val = __builtin_bit_cast(u32x4, x);
+                } else {
+                    bf16x8 x = __builtin_bit_cast(bf16x8, val), y = __builtin_bit_cast(bf16x8, rr);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = (__bf16)((float)x[j] + (float)y[j]);
+                    val = __builtin_bit_cast(u32x4, x);
+                }
+            }
+            *reinterpret_cast<u32x4*>(outp + opix * a.out_cs + co) = val;
+        }
+    }
 }
 
-template <int PREC, int MODE, int NT, int STEPS>
-static hipError_t launch_one(const ConvArgs& a, int ncb, hipStream_t s) {
-    const dim3 grid(a.tiles_x * a.tiles_y * a.B, ncb);
-    const size_t lds = conv_lds_bytes(PREC, MODE, STEPS);
-    static bool attr_done = false;
+// ---------------------------------------------------------------------------------------------
+// M_CONV, LDS-resident weights: the chunk's packed weights (9 taps x STEPS k-steps, 36 KiB for two
+// 32-channel N blocks) sit in LDS next to the halo tile, copied once per workgroup instead of being
+// streamed through the vector L1 by each of the 4 waves, so the MFMA loop issues only LDS reads.
+// The next chunk (halo tile + weights) is fetched into registers while the current one computes.
+template <int PREC, int NT, int STEPS, bool PL>
+__global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
+    using G = Geo<PREC, M_CONV, NT, STEPS>;
+    constexpr int NSEG = 9 * STEPS;
+    constexpr int NB = NT * G::BV;                       // weight vectors per lane per k-step
+    constexpr int BVEC = NSEG * G::STEPV;                // 16-B weight vectors per chunk
+    constexpr int BITER = (BVEC + 255) / 256;
+    constexpr int A_BYTES = G::TILE_BYTES * G::AV;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* smem_b = smem + A_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int H = a.H, W = a.W;
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    const size_t img_bytes = (size_t)H * W * a.cin_p * G::ESZ;
+
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpack) + (size_t)blockIdx.y * a.wstride_cb + tid;
+    const unsigned char* in0 = reinterpret_cast<const unsigned char*>(a.in);
+
+    u32x4 regs_a[G::ITER], regs_b[BITER];
+    auto load_w = [&](int c) {
+#pragma unroll
+        for (int it = 0; it < BITER; ++it) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (BVEC % 256 == 0 || tid + it * 256 < BVEC) v = wsrc[(size_t)c * BVEC + it * 256];
+            regs_b[it] = v;
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int it = 0; it < BITER; ++it)
+            if (BVEC % 256 == 0 || tid + it * 256 < BVEC)
+                *reinterpret_cast<u32x4*>(smem_b + (size_t)(tid + it * 256) * 16) = regs_b[it];
+    };
+    struct TileXY {
+        int b, y0, x0;
+    };
+    auto decode = [&](int t) {
+        TileXY q;
+        const int txi = t % a.tiles_x;
+        t /= a.tiles_x;
+        q.x0 = txi * TW;
+        q.y0 = (t % a.tiles_y) * G::TH;
+        q.b = t / a.tiles_y;
+        return q;
+    };
+
+    // persistent over tiles blockIdx.x, blockIdx.x + gridDim.x, ...: the (tile, chunk) sequence is one
+    // software pipeline, so a tile's first chunk is fetched under the previous tile's last chunk and
+    // its stores drain under the next tile's MFMAs
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    TileXY cur = decode(t);
+    stage_load<G, PREC>(regs_a, in0 + cur.b * img_bytes, 0, a.cin_p, cur.y0, cur.x0, H, W, tid);
+    load_w(0);
+    stage_store<G, PREC>(regs_a, smem, tid);
+    store_w();
+    __syncthreads();
+
+    const unsigned char* bl = smem_b + lane * 16;
+    for (;;) {
+        f32x16 acc[G::MT][NT];
+        zero_acc<G, NT>(acc);
+        const int tn = t + gridDim.x;
+        const bool have_next = tn < ntiles;
+        const TileXY nxt = decode(have_next ? tn : t);
+        for (int c = 0; c < a.nchunk; ++c) {
+            const bool last = c + 1 == a.nchunk;
+            const bool pf = (!last || have_next) && !(a.dbg & 4);
+            if (pf) {   // lands while this chunk's MFMAs run
+                const TileXY& q = last ? nxt : cur;
+                const int cn = last ? 0 : c + 1;
+                stage_load<G, PREC>(regs_a, in0 + q.b * img_bytes, cn, a.cin_p, q.y0, q.x0, H, W, tid);
+                load_w(cn);
+            }
+            if (!(a.dbg & 2)) {
+                u32x4 fa[2][G::MT][G::AV], fb[2][NB];
+                load_a<G, M_CONV>(fa[0], smem, 0, 0, wave, r, h);
+#pragma unroll
+                for (int q = 0; q < NB; ++q) fb[0][q] = *reinterpret_cast<const u32x4*>(bl + q * 1024);
+#pragma unroll
+                for (int i = 0; i < NSEG; ++i) {
+                    if (i + 1 < NSEG) {
+                        load_a<G, M_CONV>(fa[(i + 1) & 1], smem, (i + 1) / STEPS, (i + 1) % STEPS, wave, r, h);
+#pragma unroll
+                        for (int q = 0; q < NB; ++q)
+                            fb[(i + 1) & 1][q] = *reinterpret_cast<const u32x4*>(bl + ((i + 1) * NB + q) * 1024);
+                    }
+#pragma unroll
+                    for (int m = 0; m < G::MT; ++m) {
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            if constexpr (PREC == P_BF16X3) {
+                                mma_wx<PREC, PL>(acc[m][n], fb[i & 1][n * 2 + 0], fa[i & 1][m][1]);   // w_hi * x_lo
+                                mma_wx<PREC, PL>(acc[m][n], fb[i & 1][n * 2 + 1], fa[i & 1][m][0]);   // w_lo * x_hi
+                                mma_wx<PREC, PL>(acc[m][n], fb[i & 1][n * 2 + 0], fa[i & 1][m][0]);   // w_hi * x_hi
+                            } else {
+                                mma_wx<PREC, PL>(acc[m][n], fb[i & 1][n], fa[i & 1][m][0]);
+                            }
+                        }
+                    }
+                    // spread the next step's LDS reads between this step's MFMAs (one read after each MFMA)
+                    if (i + 1 < NSEG) {
+                        constexpr int NRD = G::MT * G::AV + NB;
+                        constexpr int NMF = G::MT * NT * (PREC == P_BF16X3 ? 3 : (PREC == P_FP32 ? 4 : 1));
+                        constexpr int NPAIR = NRD < NMF ? NRD : NMF;
+#pragma unroll
+                        for (int k = 0; k < NPAIR; ++k) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                        }
+                        if constexpr (NMF > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NPAIR, 0);
+                        if constexpr (NRD > NPAIR) __builtin_amdgcn_sched_group_barrier(0x100, NRD - NPAIR, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (pf && !last) {
+                __syncthreads();   // every wave is done reading this chunk
+                stage_store<G, PREC>(regs_a, smem, tid);
+                store_w();
+                __syncthreads();
+            }
+        }
+        // wide, vector-aligned outputs leave through the LDS transpose; narrow ones (flow, image) directly
+        const bool via_lds = PL && !(a.dbg & 8) && a.cout_store % 8 == 0 && a.out_cs % 8 == 0 &&
+                             (!a.res || a.res_cs % 8 == 0) && a.act != A_TANH;
+        if (a.dbg & 1) {   // ablation: keep the accumulators alive, store nothing
+#pragma unroll
+            for (int m = 0; m < G::MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) keep_alive(acc[m][n]);
+        } else if (via_lds) {
+            if constexpr (PL) {
+                __syncthreads();   // the tile's last chunk has been read by every wave: LDS becomes scratch
+                if (a.out_f32) epilogue_lds<G, NT, float>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem);
+                else epilogue_lds<G, NT, __bf16>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem);
+            }
+        } else {
+            epilogue<G, M_CONV, NT, PL>(acc, a, 0, cur.b, cur.y0, cur.x0, wave, r, h);
+        }
+        if (!have_next) break;
+        if (!(a.dbg & 4)) {
+            __syncthreads();   // scratch reads / last chunk reads are done
+            stage_store<G, PREC>(regs_a, smem, tid);
+            store_w();
+            __syncthreads();
+        }
+        t = tn;
+        cur = nxt;
+    }
+}
+
+size_t conv_lds_bytes(int prec, int mode, int nt, int steps) {
+    const int th = mode == M_CONV ? 8 : 4, hb = mode == M_CONV ? 1 : 0;
+    const size_t tile = (size_t)(th + 1 + hb) * (TW + 1 + hb) * (32 * steps + 16);
+    const size_t a = prec == P_BF16X3 ? 2 * tile : tile;
+    if (mode == M_CONVT) return a;
+    const size_t bv = prec == P_BF16X3 ? 2 : 1;
+    const size_t ab = a + (size_t)9 * steps * nt * bv * 1024;   // + the chunk's weights
+    const size_t scratch = (size_t)4 * 64 * (nt * 32 * 4 + 16);  // epilogue_lds, fp32 rows (the larger case)
+    return ab > scratch ? ab : scratch;
+}
+
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <typename K>
+static hipError_t launch_k(K kernel, size_t lds, const ConvArgs& a, int ncb, hipStream_t s, bool& attr_done,
+                           bool persistent) {
     if (lds > 64 * 1024 && !attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<PREC, MODE, NT, STEPS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_kernel<PREC, MODE, NT, STEPS>), grid, dim3(256), lds, s, a);
+    int gx = a.tiles_x * a.tiles_y * a.B;
+    if (persistent) {   // two workgroups per CU, every workgroup the same number of tiles (+-1)
+        const int maxwg = std::max(1, 2 * num_cus() / ncb);
+        const int iters = (gx + maxwg - 1) / maxwg;
+        gx = (gx + iters - 1) / iters;
+    }
+    hipLaunchKernelGGL(kernel, dim3(gx, ncb), dim3(256), lds, s, a);
     return hipGetLastError();
+}
+
+template <int PREC, int MODE, int NT, int STEPS>
+static hipError_t launch_one(const ConvArgs& a, int ncb, hipStream_t s) {
+    static bool attr_done = false;
+    const size_t lds = conv_lds_bytes(PREC, MODE, NT, STEPS);
+    if constexpr (MODE == M_CONV) {
+        return launch_k(&conv3x3_lds_kernel<PREC, NT, STEPS, true>, lds, a, ncb, s, attr_done, true);
+    } else {
+        return launch_k(&conv3x3_kernel<PREC, MODE, NT, STEPS>, lds, a, ncb, s, attr_done, false);
+    }
 }
 
 template <int PREC, int MODE, int NT>
 static hipError_t launch_steps(int steps, const ConvArgs& a, int ncb, hipStream_t s) {
     constexpr int MAXS = prec_maxsteps(PREC, MODE);
     if (steps == 1) return launch_one<PREC, MODE, NT, 1>(a, ncb, s);
-    if (steps == 2) return launch_one<PREC, MODE, NT, 2>(a, ncb, s);
+    if constexpr (MAXS >= 2) {
+        if (steps == 2) return launch_one<PREC, MODE, NT, 2>(a, ncb, s);
+    }
     if constexpr (MAXS >= 4) {
         if (steps == 4) return launch_one<PREC, MODE, NT, 4>(a, ncb, s);
     }

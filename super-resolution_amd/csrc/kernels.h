@@ -31,19 +31,21 @@ struct ConvArgs {
     int tiles_x, tiles_y;
     int nchunk;            // number of input-channel chunks
     int wstride_cb;        // 16-byte vectors of wpack per output-channel block
+    int dbg;               // ablation switches for tools/conv_bench.py (0 in production)
 };
 
 // steps per chunk / chunk geometry, shared by the packer and the kernel
 __host__ __device__ constexpr int prec_ks(int prec) { return prec == P_FP32 ? 8 : 16; }      // channels per k-step
-// conv: chunks of at most 128 payload bytes per pixel (x3: 64 B in each of the hi and lo tiles);
+// conv: chunks of 16 (fp32, bf16x3) or 32 (bf16) input channels, so that the halo tile plus the
+// chunk's weights (36 KiB) let two workgroups share a CU's LDS;
 // transposed conv: all 64 input channels of this network's layers in ONE chunk
 __host__ __device__ constexpr int prec_maxsteps(int prec, int mode) {
-    return mode == M_CONV ? (prec == P_BF16X3 ? 2 : 4) : (prec == P_FP32 ? 8 : 4);
+    return mode == M_CONV ? (prec == P_BF16X3 ? 1 : 2) : (prec == P_FP32 ? 8 : 4);
 }
 
 // host-side launchers (conv_mfma.hip)
 hipError_t launch_conv(int prec, int mode, int nt, int steps, const ConvArgs& a, int ncb, hipStream_t s);
-size_t conv_lds_bytes(int prec, int mode, int steps);
+size_t conv_lds_bytes(int prec, int mode, int nt, int steps);
 
 // element-wise / gather kernels (fused_ops.hip).  act_bf16: activations are bf16.
 hipError_t launch_fnet_input(const float* lr_t, const float* lr_tm1, void* out, int act_bf16,

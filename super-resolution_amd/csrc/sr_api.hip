@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -19,6 +20,7 @@ using namespace sr;
 namespace {
 
 thread_local std::string g_err;
+int g_conv_dbg = 0;   // ablation switches, set only by sr_bench_conv
 
 struct HostTensor {
     std::string name;
@@ -76,6 +78,7 @@ struct sr_ctx {
     // recurrent state
     bool clip_active = false;
     int clip_B = 0, cur = 0;
+    int trunk_sub = 0;   // clips per trunk sub-batch (0 = whole batch)
     // profiling
     bool prof_on = false;
     std::vector<ProfEntry> prof;
@@ -285,6 +288,7 @@ int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, con
     a.tiles_y = (io.H + th - 1) / th;
     a.nchunk = L.nchunk;
     a.wstride_cb = L.wstride_cb;
+    a.dbg = g_conv_dbg;
     if (io.cout_store > L.ncb * L.nt * 32) return fail(c, SR_ERR_ARG, "%s: cout_store out of range", name);
     const double px = (double)B * io.H * io.W;
     const double esz_in = prec == P_BF16 ? 2 : 4, esz_out = io.out_f32 ? 4 : 2;
@@ -394,22 +398,34 @@ int run_fnet(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, float
     return run_conv(c, P, st, c->fnet[13], B, {b("a0"), H, W, d_flow, 2, 2, 1, nullptr, 0, A_TANH}, "fnet.conv14");
 }
 
-// SRNet: reference layers.py:66-76; input already concatenated into buf "s_in"
+// SRNet: reference layers.py:66-76; input already concatenated into buf "s_in".
+// The LR-resolution trunk (head + 10 residual blocks) runs over sub-batches of `trunk_sub` clips so
+// that its two ping-pong activation tensors stay resident in the 256 MiB Infinity Cache between
+// layers instead of streaming through HBM 41 times per frame.
 int run_srnet(sr_ctx* c, int B, float* d_out) {
     const int P = c->prec, af = c->prec == P_BF16 ? 0 : 1;
     hipStream_t st = c->stream;
     const int H = c->h, W = c->w;
-    auto b = [&](const char* n) { return c->buf[n]; };
-    int rc = run_conv(c, P, st, c->srnet[0], B, {b("s_in"), H, W, b("sx"), 64, 64, af, nullptr, 0, A_RELU}, "srnet.head");
-    if (rc) return rc;
-    for (int r = 0; r < 10; ++r) {
-        rc = run_conv(c, P, st, c->srnet[1 + 2 * r], B, {b("sx"), H, W, b("sy"), 64, 64, af, nullptr, 0, A_RELU}, "srnet.res");
+    const size_t es = af ? 4 : 2;
+    const int sub = c->trunk_sub > 0 ? c->trunk_sub : B;
+    for (int b0 = 0; b0 < B; b0 += sub) {
+        const int nb = b0 + sub <= B ? sub : B - b0;
+        const size_t off = (size_t)b0 * H * W * 64 * es;
+        unsigned char* s_in = (unsigned char*)c->buf["s_in"] + off;
+        unsigned char* sx = (unsigned char*)c->buf["sx"] + off;
+        unsigned char* sy = (unsigned char*)c->buf["sy"] + off;
+        int rc = run_conv(c, P, st, c->srnet[0], nb, {s_in, H, W, sx, 64, 64, af, nullptr, 0, A_RELU}, "srnet.head");
         if (rc) return rc;
-        // x = x + conv(y): each thread reads then writes its own element, in place is safe
-        rc = run_conv(c, P, st, c->srnet[2 + 2 * r], B, {b("sy"), H, W, b("sx"), 64, 64, af, b("sx"), 64, A_NONE}, "srnet.res");
-        if (rc) return rc;
+        for (int r = 0; r < 10; ++r) {
+            rc = run_conv(c, P, st, c->srnet[1 + 2 * r], nb, {sx, H, W, sy, 64, 64, af, nullptr, 0, A_RELU}, "srnet.res");
+            if (rc) return rc;
+            // x = x + conv(y): each thread reads then writes its own element, in place is safe
+            rc = run_conv(c, P, st, c->srnet[2 + 2 * r], nb, {sy, H, W, sx, 64, 64, af, sx, 64, A_NONE}, "srnet.res");
+            if (rc) return rc;
+        }
     }
-    rc = run_conv(c, P, st, c->srnet[21], B, {b("sx"), H, W, b("up1"), 64, 64, af, nullptr, 0, A_RELU}, "srnet.up1");
+    auto b = [&](const char* n) { return c->buf[n]; };
+    int rc = run_conv(c, P, st, c->srnet[21], B, {b("sx"), H, W, b("up1"), 64, 64, af, nullptr, 0, A_RELU}, "srnet.up1");
     if (rc) return rc;
     rc = run_conv(c, P, st, c->srnet[22], B, {b("up1"), 2 * H, 2 * W, b("up2"), 64, 64, af, nullptr, 0, A_RELU}, "srnet.up2");
     if (rc) return rc;
@@ -481,6 +497,7 @@ int sr_create(sr_ctx** out, int device, int h, int w, int ch, int scale, int max
     c->max_batch = max_batch;
     c->prec = dtype;
     c->model = model;
+    if (const char* e = getenv("SR_TRUNK_SUB")) c->trunk_sub = atoi(e);
     int rc = SR_OK;
     auto bail = [&](int code) {
         g_err = c->err;
@@ -895,7 +912,8 @@ int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, in
     const int mode = transposed ? M_CONVT : M_CONV;
     ConvLayer L;
     plan_layer(L, dtype, mode, Cin, Cout);
-    struct Guard { ConvLayer& l; ~Guard() { free_layer(l); } } guard{L};
+    struct Guard { ConvLayer& l; ~Guard() { free_layer(l); g_conv_dbg = 0; } } guard{L};
+    if (const char* e = getenv("SR_CONV_DBG")) g_conv_dbg = atoi(e);
     std::vector<float> w((size_t)9 * Cin * Cout), bias(Cout, 0.01f);
     uint32_t st = 12345u;
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 65536.0f - 0.5f; };
