@@ -1,0 +1,134 @@
+"""Frame-Recurrent Video Super-Resolution on MI355X: drop-in for reference FRVSR.py.
+
+Same class, constructor and stage methods as the reference (FRVSR.py:19-26, build :27,
+train :76, eval :205, run :379); the generator graph of FRVSR.py:55-66 is one native
+context (libsr_hip.so), reachable through the same attributes:
+``frvsr, fnet, srnet, upscaling, hr_warp, lr_warp, space2depth``.
+
+eval() keeps the reference's recurrent driver semantics (FRVSR.py:231-234, 280-309):
+rows x cols independent tiles batched through one step, zero initial state, estimate
+state := output, previous LR := current tiles, timing bracket around the step, PSNR
+every 10th frame, ``metrics.txt`` with the reference's columns.  Differences, on purpose
+(SURVEY.md Appendix B): state is reset per clip, the mean PSNR divides by the number of
+samples actually summed, clips are .npy arrays (video decode / SSIM / YOLO are out of scope).
+"""
+import datetime
+import os
+
+import numpy as np
+
+from layers import (FNet, GeneratorCore, GeneratorModel, Space2Depth, SRNet, Upscaling, Warp)
+from utils import (box_downscale, denormalize, get_videos, load_clip, merge_tiles, normalize, psnr,
+                   shard_range, split_tiles)
+
+
+class FrameRecurrentVideoSR(object):
+    model_kind = 'frvsr'
+
+    def __init__(self, lr_shape, hr_shape, output_dir, configs):
+        self.lr_shape = tuple(lr_shape)
+        self.hr_shape = tuple(hr_shape)
+        self.output_dir = output_dir
+        self.configs = configs
+
+    def _check_shapes(self):
+        if self.lr_shape[0] * 4 != self.hr_shape[0] or self.lr_shape[1] * 4 != self.hr_shape[1]:
+            raise ValueError('Incompatible resolutions with upscale x4.')
+        if self.lr_shape[0] % 8 or self.lr_shape[1] % 8:
+            raise ValueError('low resolution height and width must be multiples of 8 '
+                             '(FNet pools 3x and upsamples 3x; reference layers.py:31-41)')
+
+    def build(self):
+        self._check_shapes()
+        dtype = (self.configs.get('dtype') or 'fp32') if isinstance(self.configs, dict) else 'fp32'
+        device = int(os.environ.get('LOCAL_RANK', '0'))
+        self.core = GeneratorCore(self.lr_shape, model=self.model_kind, dtype=dtype, device=device)
+        print('[INFO] Creating FNet ...')
+        self.fnet = FNet(self.lr_shape, core=self.core).build()
+        print('[INFO] Creating SRNet ...')
+        self.srnet = SRNet(self.lr_shape, core=self.core).build()
+        self.upscaling = Upscaling(self.lr_shape).build()
+        self.hr_warp = Warp(self.hr_shape, 1).build()
+        self.lr_warp = Warp(self.lr_shape, 2).build()
+        self.space2depth = Space2Depth(self.hr_shape).build()
+        self.frvsr = GeneratorModel(self.core, 'FRVSR')
+        print('[INFO] Frame-Recurrent Video Super Resolution ready.')
+
+    # the model object holding the generator ('frvsr' here, 'generator' in TecoGAN)
+    def _generator(self):
+        return self.frvsr
+
+    def _load_pretrained(self):
+        pre = self.configs['cnn'].get('pretrained_model')
+        if pre:
+            path = pre if os.path.isabs(pre) else os.path.join(self.configs.get('root_dir', './'), pre)
+            print('[INFO] Loading pretrained model ...')
+            self._generator().load_weights(path)
+
+    def train(self):
+        raise NotImplementedError(
+            'training (reference FRVSR.py:76-202) is not part of this round: backward kernels and the '
+            'RCCL gradient all-reduce are the next rows of the scope table (SURVEY.md section 8 f)')
+
+    def run(self):
+        raise NotImplementedError('the webcam / video demo UI (reference FRVSR.py:379-536) is out of scope')
+
+    # ------------------------------------------------------------------ evaluation
+    def super_resolve_clip(self, lr_frames, hr_frames=None, name='clip', metrics_file=None):
+        """lr_frames [T, rows*h, cols*w, 3] float32 in [0,1] -> estimated [T, rows*4h, cols*4w, 3].
+        Returns (frames, stats) with stats = dict(psnr=[...every 10th frame...], ms=[...per frame...])."""
+        rows = int(self.configs['data'].get('rows', 1))
+        cols = int(self.configs['data'].get('cols', 1))
+        h, w, _ = self.lr_shape
+        T = lr_frames.shape[0]
+        if lr_frames.shape[1:] != (rows * h, cols * w, 3):
+            raise ValueError(f'expected LR frames of shape {(rows * h, cols * w, 3)}, got {lr_frames.shape[1:]}')
+        gen = self._generator()
+        gen.clip_begin(rows * cols)            # zero state for prev LR tiles and prev estimates
+        out = np.empty((T, rows * 4 * h, cols * 4 * w, 3), np.float32)
+        stats = {'psnr': [], 'ms': []}
+        for t in range(T):
+            tiles = split_tiles(lr_frames[t], rows, cols, h, w)
+            t0 = datetime.datetime.now()
+            est_tiles = gen.clip_push(tiles)
+            ms = (datetime.datetime.now() - t0).total_seconds() * 1000
+            out[t] = merge_tiles(est_tiles, rows, cols)
+            stats['ms'].append(ms)
+            if t % 10 == 0 and hr_frames is not None:
+                p = psnr(hr_frames[t], out[t])
+                stats['psnr'].append(p)
+                if metrics_file is not None:
+                    metrics_file.write('Video:\t%s\tFrame:\t%d\tInference time:\t%d\tPSNR:\t%f\n' % (name, t, ms, p))
+        return out, stats
+
+    def eval(self):
+        self._load_pretrained()
+        out_dir = self.configs['eval']['output_dir']
+        os.makedirs(out_dir, exist_ok=True)
+        rank = int(os.environ.get('RANK', '0'))
+        world = int(os.environ.get('WORLD_SIZE', '1'))
+        clips = get_videos(self.configs)
+        lo, hi = shard_range(len(clips), world, rank)       # clips are independent: shard, no collective
+        rows = int(self.configs['data'].get('rows', 1))
+        cols = int(self.configs['data'].get('cols', 1))
+        H, W = self.hr_shape[0] * rows, self.hr_shape[1] * cols
+        total, n = 0.0, 0
+        with open(os.path.join(out_dir, 'metrics.txt' if world == 1 else 'metrics_rank%d.txt' % rank), 'w+') as f:
+            for path in clips[lo:hi]:
+                clip = load_clip(path)
+                hr = normalize(clip) if clip.dtype == np.uint8 else clip.astype(np.float32)
+                if hr.shape[1:3] != (H, W):
+                    raise ValueError(f'{path}: frames are {hr.shape[1:3]}, the configured HR canvas is {(H, W)}')
+                lr = box_downscale(hr, 4)
+                est, stats = self.super_resolve_clip(lr, hr, os.path.basename(path), f)
+                np.save(os.path.join(out_dir, os.path.basename(path)), denormalize(est))
+                total += sum(stats['psnr'])
+                n += len(stats['psnr'])
+                f.write('\n')
+                print('[INFO] %s: %d frames, FRVSR inference %.2f ms/frame, PSNR %.3f' % (
+                    os.path.basename(path), len(est), float(np.mean(stats['ms'])),
+                    float(np.mean(stats['psnr'])) if stats['psnr'] else float('nan')))
+            mean_psnr = total / n if n else float('nan')
+            f.write('Total PSNR:\t%f' % mean_psnr)
+        print('\n[INFO] Avg. FRVSR PSNR: %f' % mean_psnr)
+        return mean_psnr

@@ -1,0 +1,81 @@
+"""Host helpers of the drop-in API (reference utils.py:24-71).
+
+normalize / denormalize / psnr keep the reference's exact numpy semantics (PSNR is the
+parity metric of BASELINE.json).  Video decoding (cv2), SSIM (scikit-image) and the VGG /
+YOLO metrics are third-party and out of scope of this path: clips are
+numpy arrays here.
+"""
+import math
+import os
+
+import numpy as np
+
+
+def get_videos(configs):
+    """Files of the comma-separated directories in configs['data']['videos'] (reference utils.py:24-31)."""
+    found = []
+    for d in str(configs['data']['videos']).replace(' ', '').split(','):
+        if not d:
+            continue
+        for f in sorted(os.listdir(d)):
+            full = os.path.join(d, f)
+            if os.path.isfile(full):
+                found.append(full)
+    return found
+
+
+def load_clip(path):
+    """A clip file is a .npy array [T, H, W, 3], uint8 (0..255) or float in [0,1]."""
+    if not path.lower().endswith('.npy'):
+        raise ValueError(f"{path}: only .npy clips are supported (video decoding via OpenCV is outside "
+                         "the scope of this path; convert frames to a [T,H,W,3] array)")
+    clip = np.load(path, allow_pickle=False)
+    if clip.ndim != 4 or clip.shape[-1] != 3:
+        raise ValueError(f"{path}: expected an array of shape [T,H,W,3], got {clip.shape}")
+    return clip
+
+
+def normalize(input_data):
+    return input_data.astype(np.float32) / 255.0
+
+
+def denormalize(input_data):
+    input_data = input_data * 255.0
+    return input_data.astype(np.uint8)          # truncation, like the reference
+
+
+def psnr(img1, img2):
+    mse = np.mean((img1 - img2) ** 2)
+    if mse == 0:
+        return 100
+    pixel_max = 1.0
+    return 20 * math.log10(pixel_max / math.sqrt(mse))
+
+
+def box_downscale(hr, scale=4):
+    """HR -> LR stand-in for the reference's GaussianBlur + cubic resize (cv2, FRVSR.py:274-277):
+    a plain scale x scale box average.  Used only to synthesise LR inputs from HR clips."""
+    T, H, W, C = hr.shape
+    return hr.reshape(T, H // scale, scale, W // scale, scale, C).mean(axis=(2, 4)).astype(np.float32)
+
+
+def split_tiles(frame, rows, cols, th, tw):
+    """rows*cols independent tiles, row-major i*cols+j, no halo (reference FRVSR.py:280-289)."""
+    return np.stack([frame[i * th:(i + 1) * th, j * tw:(j + 1) * tw] for i in range(rows) for j in range(cols)])
+
+
+def merge_tiles(tiles, rows, cols):
+    """Inverse of split_tiles for the estimated tiles (reference FRVSR.py:299-301)."""
+    _, th, tw, c = tiles.shape
+    out = np.empty((rows * th, cols * tw, c), tiles.dtype)
+    for i in range(rows):
+        for j in range(cols):
+            out[i * th:(i + 1) * th, j * tw:(j + 1) * tw] = tiles[i * cols + j]
+    return out
+
+
+def shard_range(n_items, world_size, rank):
+    """Contiguous block of items for `rank` (clip c -> GPU c // ceil(C/N))."""
+    per = -(-n_items // world_size)
+    lo = min(n_items, rank * per)
+    return lo, min(n_items, lo + per)

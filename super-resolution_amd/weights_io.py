@@ -1,0 +1,113 @@
+"""Weight files for the drop-in models (reference FRVSR.py:88,193,212; TecoGAN.py:158,268,517,537).
+
+The reference stores Keras 2.2.4 ``save_weights`` HDF5 files (``demo.h5``, checkpoints).  Their
+layout: one group per top-level layer, only ``FNet`` (28 datasets) and
+``SRNet`` (48 datasets) carry weights, dataset names ``<group>/conv2d_<n>/kernel:0`` etc., and
+Keras matches them to layers BY ORDER, not by name.  This module keeps exactly that contract on
+an ordered ``[(keras_name, float32 array)]`` list and supports two containers:
+
+  * ``.h5`` / ``.hdf5``  the Keras layout, read/written with h5py WHEN h5py is importable (it is not in
+                the build image: then a clear error says so -- nothing is guessed);
+  * ``.npz``            the same names and arrays in a numpy archive plus ``__order__`` (file order).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+GROUPS = ("FNet", "SRNet")
+
+
+def _group_of(name):
+    return name.split("/")[0]
+
+
+def read_tensors(path):
+    """Ordered [(keras_name, array)] of every weight tensor in the file."""
+    ext = os.path.splitext(path)[1].lower()
+    if not os.path.exists(path):
+        raise OSError(f"Unable to open weight file {path!r}: no such file")
+    if ext == ".npz":
+        with np.load(path, allow_pickle=False) as z:
+            order = [str(n) for n in z["__order__"]] if "__order__" in z.files else [n for n in z.files]
+            return [(n, np.asarray(z[n], np.float32)) for n in order if n != "__order__"]
+    if ext in (".h5", ".hdf5"):
+        try:
+            import h5py
+        except ImportError as e:
+            raise RuntimeError(
+                f"{path}: reading Keras HDF5 weight files needs h5py, which is not installed here; "
+                "convert the file to .npz (same tensor names, see weights_io.write_tensors)") from e
+        out = []
+        with h5py.File(path, "r") as f:
+            g = f["model_weights"] if "model_weights" in f else f
+            layer_names = [n.decode() if isinstance(n, bytes) else n for n in g.attrs["layer_names"]]
+            for ln in layer_names:
+                lg = g[ln]
+                for wn in lg.attrs.get("weight_names", []):
+                    wn = wn.decode() if isinstance(wn, bytes) else wn
+                    name = wn if wn.startswith(ln + "/") else ln + "/" + wn
+                    out.append((name, np.asarray(lg[wn], np.float32)))
+        return out
+    raise ValueError(f"{path}: unsupported weight file extension {ext!r} (use .h5 or .npz)")
+
+
+def write_tensors(path, tensors):
+    tensors = [(n, np.ascontiguousarray(a, np.float32)) for n, a in tensors]
+    ext = os.path.splitext(path)[1].lower()
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    if ext == ".npz":
+        arrays = {n: a for n, a in tensors}
+        arrays["__order__"] = np.array([n for n, _ in tensors])
+        with open(path, "wb") as fh:
+            np.savez(fh, **arrays)
+        return
+    if ext in (".h5", ".hdf5"):
+        try:
+            import h5py
+        except ImportError as e:
+            raise RuntimeError(f"{path}: writing Keras HDF5 weight files needs h5py (not installed); "
+                               "use a .npz path") from e
+        with h5py.File(path, "w") as f:
+            groups = []
+            for n, _ in tensors:
+                if _group_of(n) not in groups:
+                    groups.append(_group_of(n))
+            f.attrs["layer_names"] = [g.encode() for g in groups]
+            f.attrs["backend"] = b"tensorflow"
+            f.attrs["keras_version"] = b"2.2.4"
+            for g in groups:
+                lg = f.create_group(g)
+                names = [n for n, _ in tensors if _group_of(n) == g]
+                lg.attrs["weight_names"] = [n.encode() for n in names]
+                for n, a in tensors:
+                    if _group_of(n) == g:
+                        lg.create_dataset(n, data=a)
+        return
+    raise ValueError(f"{path}: unsupported weight file extension {ext!r} (use .h5 or .npz)")
+
+
+def load_into(model, path):
+    """Keras semantics: tensors of the groups this model owns, matched by position and shape."""
+    tensors = read_tensors(path)
+    want = model.named_weights() if hasattr(model, "named_weights") else []
+    prefixes = []
+    for n, _ in want:
+        if _group_of(n) not in prefixes:
+            prefixes.append(_group_of(n))
+    have = [(n, a) for n, a in tensors if _group_of(n) in prefixes]
+    if len(have) != len(want):
+        raise ValueError(f"{path}: holds {len(have)} tensors for {prefixes}, the model {model.name} "
+                         f"expects {len(want)}")
+    ordered = []
+    for p in prefixes:      # keep each group's own order, groups in model order
+        ordered += [a for n, a in have if _group_of(n) == p]
+    for (wn, wa), a in zip(want, ordered):
+        if tuple(a.shape) != tuple(wa.shape):
+            raise ValueError(f"{path}: tensor for {wn} has shape {tuple(a.shape)}, expected {tuple(wa.shape)}")
+    model.set_weights(ordered)
+
+
+def save_from(model, path):
+    write_tensors(path, model.named_weights() if hasattr(model, "named_weights") else [])

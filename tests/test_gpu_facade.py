@@ -1,0 +1,82 @@
+"""The drop-in Python API on the GPU: reference-style predict calls, sub-models, eval driver."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_numpy as rn
+from oracle import ref_torch as rt
+
+pytestmark = pytest.mark.gpu
+
+
+def build(kind, lr, tmp, weights, rows=1, cols=1, dtype='fp32'):
+    from FRVSR import FrameRecurrentVideoSR
+    from TecoGAN import TecoGAN
+    cfg = {'root_dir': str(tmp), 'dtype': dtype, 'data': {'rows': rows, 'cols': cols, 'videos': str(tmp / 'clips')},
+           'cnn': {'model': kind, 'pretrained_model': 'w.npz'}, 'eval': {'output_dir': str(tmp / 'out')}}
+    import weights_io
+    weights_io.write_tensors(str(tmp / 'w.npz'), list(weights.items()))
+    cls = FrameRecurrentVideoSR if kind == 'frvsr' else TecoGAN
+    m = cls(lr, (4 * lr[0], 4 * lr[1], 3), str(tmp), cfg)
+    m.build()
+    return m
+
+
+def test_reference_style_predict_calls(tmp_path, weights7):
+    m = build('frvsr', (16, 24, 3), tmp_path, weights7)
+    m.frvsr.load_weights(str(tmp_path / 'w.npz'))
+    lr_t = rn.synth_clip(1, 1, 16, 24)
+    lr_tm1 = rn.synth_clip(2, 1, 16, 24)
+    est_prev = np.zeros((1, 64, 96, 3))                      # float64 zeros like FRVSR.py:233-234
+    est, lr_warp = m.frvsr.predict([lr_t, lr_tm1, est_prev])
+    want, want_lw = rt.generator_step(weights7, lr_t, lr_tm1, est_prev)
+    assert est.dtype == np.float32 and np.abs(est - want).max() <= 1e-3
+    assert np.abs(lr_warp - want_lw).max() <= 1e-3
+    # sub-models reproduce the graph: fnet -> upscaling -> warp -> space2depth -> srnet (FRVSR.py:58-63)
+    flow = m.fnet.predict([lr_t, lr_tm1])
+    f_hr = m.upscaling.predict(flow)
+    warped = m.hr_warp.predict([est.astype(np.float32), f_hr])
+    s_s = m.space2depth.predict(warped)
+    est2 = m.srnet.predict([lr_t, s_s])
+    est2_ref, _ = m.frvsr.predict([lr_t, lr_tm1, est])
+    assert np.abs(est2 - est2_ref).max() <= 1e-4
+    lw = m.lr_warp.predict([lr_tm1, flow])
+    assert np.abs(lw - lr_warp).max() <= 1e-5
+
+
+def test_tecogan_generator_and_hr_warping(tmp_path, weights7):
+    t = build('tecogan', (16, 16, 3), tmp_path, weights7)
+    t.generator.load_weights(str(tmp_path / 'w.npz'))
+    lr_t, lr_tm1 = rn.synth_clip(3, 1, 16, 16), rn.synth_clip(4, 1, 16, 16)
+    est_prev = rn.uniform01(5, 64 * 64 * 3).reshape(1, 64, 64, 3).astype(np.float32)
+    est, _ = t.generator.predict([lr_t, lr_tm1, est_prev])
+    want, _ = rt.generator_step(weights7, lr_t, lr_tm1, est_prev, model='tecogan')
+    assert np.abs(est - want).max() <= 1e-3
+    taps = {}
+    rt.generator_step(weights7, lr_t, lr_tm1, est_prev, taps=taps)
+    hw = t.hr_warping.predict([lr_t, lr_tm1, est_prev])      # single array, not a list (TecoGAN.py:83-84)
+    assert isinstance(hw, np.ndarray) and np.abs(hw - taps['hr_warp']).max() <= 2e-4
+
+
+def test_eval_driver_tiles_state_and_metrics(tmp_path, weights7):
+    """2x2 tiles of 16x16 LR, 11 frames: tiling (no halo), per-tile recurrence, metrics.txt columns."""
+    m = build('frvsr', (16, 16, 3), tmp_path, weights7, rows=2, cols=2)
+    os.makedirs(tmp_path / 'clips')
+    hr = rn.synth_clip(7, 11, 128, 128, scale=4)
+    np.save(tmp_path / 'clips' / 'a.npy', (hr * 255).astype(np.uint8))
+    mean_psnr = m.eval()
+    text = open(tmp_path / 'out' / 'metrics.txt').read()
+    assert text.count('Video:\ta.npy\tFrame:\t') == 2 and 'Inference time:' in text and 'Total PSNR:' in text
+    est = np.load(tmp_path / 'out' / 'a.npy')
+    assert est.shape == (11, 128, 128, 3) and est.dtype == np.uint8
+    # oracle for one tile (row 1, col 0), full recurrence
+    import utils
+    hr_n = utils.normalize((hr * 255).astype(np.uint8))
+    lr = utils.box_downscale(hr_n, 4)
+    tile = lr[:, 16:32, 0:16][:, None]
+    want = rt.run_clip(weights7, tile)
+    got = est[:, 64:128, 0:64].astype(np.float32)
+    assert np.abs(got - np.floor(want[:, 0] * 255.0)).max() <= 1.0      # uint8 truncation of values within 1e-3
+    frames_psnr = [utils.psnr(hr_n[t], est[t].astype(np.float32) / 255.0) for t in (0, 10)]
+    assert abs(mean_psnr - np.mean(frames_psnr)) < 0.05

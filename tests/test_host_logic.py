@@ -1,0 +1,165 @@
+"""Host-side logic of the drop-in facade (no GPU): names, weight layout, files, tiling, config."""
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+import layers
+import main as sr_main
+import utils
+import weights_io
+from FRVSR import FrameRecurrentVideoSR
+from TecoGAN import TecoGAN
+from oracle import ref_numpy as rn
+
+CFG = {'root_dir': './', 'data': {'rows': 2, 'cols': 2}, 'cnn': {'model': 'frvsr', 'pretrained_model': None}}
+
+
+def test_weight_specs_match_oracle_layout():
+    assert layers.weight_specs() == rn.weight_specs()
+    assert len(layers.weight_specs()) == 76
+
+
+def test_model_attributes_and_names():
+    m = FrameRecurrentVideoSR((64, 64, 3), (256, 256, 3), '/tmp/o', CFG)
+    m.build()
+    # attribute and model names of reference FRVSR.py:30-50, layers.py:48,79,92,116,139
+    assert [m.fnet.name, m.srnet.name, m.upscaling.name, m.hr_warp.name, m.lr_warp.name, m.space2depth.name] == \
+        ['FNet', 'SRNet', 'Upscaling_0', 'Warp_1', 'Warp_2', 'Space_to_Depth']
+    assert m.frvsr.count_params() == 2589093
+    assert m.fnet.count_params() == 1745506 and m.srnet.count_params() == 843587
+    t = TecoGAN((64, 64, 3), (256, 256, 3), '/tmp/o', dict(CFG, cnn={'model': 'tecogan'}))
+    t.build()
+    assert t.generator.name == 'Generator' and t.hr_warping.name == 'HR_Warping'
+    assert t.bicubic_upscale.name == 'Upscaling_1' and not hasattr(t, 'frvsr')
+    assert t.core.model == 'tecogan'
+
+
+def test_fresh_model_uses_keras_default_initialisers():
+    core = layers.GeneratorCore((16, 16, 3), seed=1)
+    for name, a in core.tensors:
+        if a.ndim == 4:
+            lim = np.sqrt(6.0 / (9 * a.shape[2] + 9 * a.shape[3]))
+            assert np.abs(a).max() <= lim and np.abs(a).max() > 0.5 * lim
+        else:
+            assert not a.any()
+
+
+def test_shape_checks():
+    with pytest.raises(ValueError):
+        FrameRecurrentVideoSR((60, 64, 3), (240, 256, 3), '/tmp/o', CFG).build()      # 60 % 8
+    with pytest.raises(ValueError):
+        FrameRecurrentVideoSR((64, 64, 3), (128, 128, 3), '/tmp/o', CFG).build()      # not x4
+    with pytest.raises(ValueError):
+        layers.GeneratorCore((16, 16, 1))
+
+
+def test_weights_npz_roundtrip_and_position_matching(tmp_path, weights7):
+    m = FrameRecurrentVideoSR((16, 16, 3), (64, 64, 3), str(tmp_path), CFG)
+    m.build()
+    m.frvsr.set_weights(list(weights7.values()))
+    p = str(tmp_path / 'w.npz')
+    m.frvsr.save_weights(p)
+    tensors = weights_io.read_tensors(p)
+    assert [n for n, _ in tensors] == list(weights7.keys())
+    m2 = FrameRecurrentVideoSR((16, 16, 3), (64, 64, 3), str(tmp_path), CFG)
+    m2.build()
+    m2.frvsr.load_weights(p)
+    for a, b in zip(m2.frvsr.get_weights(), weights7.values()):
+        np.testing.assert_array_equal(a, b)
+    # sub-models see the shared variables (reference: fnet/srnet share weights with frvsr)
+    np.testing.assert_array_equal(m2.fnet.get_weights()[0], weights7['FNet/conv2d_1/kernel:0'])
+    np.testing.assert_array_equal(m2.srnet.get_weights()[-1], weights7['SRNet/conv2d_36/bias:0'])
+    # FRVSR and TecoGAN generator files are interchangeable (same two weighted sub-models)
+    t = TecoGAN((16, 16, 3), (64, 64, 3), str(tmp_path), CFG)
+    t.build()
+    t.generator.load_weights(p)
+    np.testing.assert_array_equal(t.generator.get_weights()[5], list(weights7.values())[5])
+    # a sub-model file holds only its group
+    pf = str(tmp_path / 'fnet.npz')
+    m2.fnet.save_weights(pf)
+    assert len(weights_io.read_tensors(pf)) == 28
+    # names with other numeric suffixes still load (Keras matches by position)
+    renamed = [(n.replace('conv2d_', 'conv2d_1'), a) for n, a in tensors]
+    weights_io.write_tensors(str(tmp_path / 'r.npz'), renamed)
+    m2.frvsr.load_weights(str(tmp_path / 'r.npz'))
+    # wrong shapes / counts are rejected
+    bad = list(tensors)
+    bad[0] = (bad[0][0], np.zeros((3, 3, 6, 31), np.float32))
+    weights_io.write_tensors(str(tmp_path / 'bad.npz'), bad)
+    with pytest.raises(ValueError):
+        m2.frvsr.load_weights(str(tmp_path / 'bad.npz'))
+    weights_io.write_tensors(str(tmp_path / 'short.npz'), tensors[:20])
+    with pytest.raises(ValueError):
+        m2.frvsr.load_weights(str(tmp_path / 'short.npz'))
+    with pytest.raises(OSError):
+        m2.frvsr.load_weights(str(tmp_path / 'missing.npz'))
+
+
+def test_h5_needs_h5py_and_says_so(tmp_path):
+    try:
+        import h5py  # noqa: F401
+        pytest.skip("h5py present")
+    except ImportError:
+        pass
+    p = tmp_path / 'demo.h5'
+    p.write_bytes(b'\x89HDF\r\n\x1a\n')
+    with pytest.raises(RuntimeError, match="h5py"):
+        weights_io.read_tensors(str(p))
+
+
+def test_utils_semantics():
+    x = np.array([0, 127, 255], np.uint8)
+    assert utils.normalize(x).dtype == np.float32 and utils.normalize(x)[2] == 1.0
+    assert utils.denormalize(np.array([0.999, 0.5])).tolist() == [254, 127]      # truncation (utils.py:61-63)
+    a = np.full((2, 2, 3), 0.25, np.float32)
+    assert utils.psnr(a, a) == 100
+    assert abs(utils.psnr(a, a + 0.1) - rn.psnr(a, a + 0.1)) < 1e-12
+
+
+def test_tiling_roundtrip_and_order():
+    frame = np.arange(2 * 4 * 3 * 6 * 3, dtype=np.float32).reshape(8, 18, 3)
+    tiles = utils.split_tiles(frame, 2, 3, 4, 6)
+    assert tiles.shape == (6, 4, 6, 3)
+    np.testing.assert_array_equal(tiles[1 * 3 + 2], frame[4:8, 12:18])          # index i*cols + j
+    np.testing.assert_array_equal(utils.merge_tiles(tiles, 2, 3), frame)
+
+
+def test_shard_range_contiguous_blocks():
+    assert [utils.shard_range(128, 8, r) for r in range(8)] == [(16 * r, 16 * r + 16) for r in range(8)]
+    assert [utils.shard_range(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert utils.shard_range(2, 4, 3) == (2, 2)
+
+
+def test_yaml_surface(tmp_path):
+    for name in ('FRVSR_example.yaml', 'TecoGAN_example.yaml', '180p.yaml'):
+        cfg = yaml.safe_load(open(os.path.join(os.path.dirname(layers.__file__), 'options', name)))
+        lr, hr = sr_main.shapes_from_config(cfg)
+        assert lr[0] * 4 == hr[0] and lr[1] * 4 == hr[1]
+        model = sr_main.make_model(cfg, str(tmp_path))
+        assert type(model).__name__ == {'frvsr': 'FrameRecurrentVideoSR', 'tecogan': 'TecoGAN'}[cfg['cnn']['model']]
+    cfg['data']['high_res'] = 100
+    with pytest.raises(ValueError):
+        sr_main.shapes_from_config(cfg)
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(layers.__file__), 'options', 'FRVSR_example.yaml')))
+    cfg['cnn']['model'] = 'edvr'
+    with pytest.raises(ValueError):
+        sr_main.make_model(cfg, str(tmp_path))
+
+
+def test_out_of_scope_stages_say_so():
+    m = FrameRecurrentVideoSR((16, 16, 3), (64, 64, 3), '/tmp/o', CFG)
+    with pytest.raises(NotImplementedError):
+        m.train()
+    with pytest.raises(NotImplementedError):
+        m.run()
+
+
+def test_clip_loader_rejects_videos(tmp_path):
+    (tmp_path / 'a.mp4').write_bytes(b'0')
+    with pytest.raises(ValueError):
+        utils.load_clip(str(tmp_path / 'a.mp4'))
+    np.save(tmp_path / 'c.npy', np.zeros((2, 8, 8, 3), np.uint8))
+    assert utils.load_clip(str(tmp_path / 'c.npy')).shape == (2, 8, 8, 3)
+    assert utils.get_videos({'data': {'videos': str(tmp_path)}}) == [str(tmp_path / 'a.mp4'), str(tmp_path / 'c.npy')]
