@@ -30,6 +30,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace sr {
 
@@ -76,9 +77,9 @@ __device__ __forceinline__ void mma_wx(f32x16& acc, const u32x4& w, const u32x4&
     else mma<PREC>(acc, x, w);
 }
 
-template <int PREC, int MODE, int NT, int STEPS>
+template <int PREC, int MODE, int NT, int STEPS, int MTC = 2>
 struct Geo {
-    static constexpr int MT = MODE == M_CONV ? 2 : 1;        // 32-pixel row segments per wave
+    static constexpr int MT = MODE == M_CONV ? MTC : 1;      // 32-pixel row segments (tile rows) per wave
     static constexpr int TH = 4 * MT;                         // tile rows
     static constexpr int HB = MODE == M_CONV ? 1 : 0;         // bottom / right halo
     static constexpr int HROWS = TH + 1 + HB, HCOLS = TW + 1 + HB;
@@ -165,7 +166,7 @@ __device__ __forceinline__ void load_a(u32x4 (&af)[G::MT][G::AV], const unsigned
     for (int m = 0; m < G::MT; ++m) {
         int hy, hx;
         if constexpr (MODE == M_CONV) {
-            hy = 2 * wave + m + ky;
+            hy = G::MT * wave + m + ky;
             hx = r + kx;
         } else {   // out[2i+ky] += in[i] w[ky]: ky = 2 reads the pixel above / left
             hy = wave + 1 - (ky >> 1);
@@ -224,7 +225,7 @@ __device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f / (__expf
 // The weights are the MFMA's A operand and the pixels its B operand, so D has the pixel on the
 // lane (lane & 31) and 4 consecutive output channels n*32 + 8g + 4h + (0..3) in registers
 // 4g..4g+3: a lane stores 16 B (8 B for bf16) per g, and a 3-channel output row is one lane's.
-template <class G, int MODE, int NT, typename OT>
+template <class G, int MODE, int NT, typename OT, bool ADD_BIAS = true>
 __device__ __forceinline__ void epilogue_t(const f32x16 (&acc)[G::MT][NT], const ConvArgs& a, int pass, int b, int y0,
                                            int x0, int wave, int r, int h) {
     const int H = a.H, W = a.W;
@@ -241,7 +242,7 @@ __device__ __forceinline__ void epilogue_t(const f32x16 (&acc)[G::MT][NT], const
     for (int m = 0; m < G::MT; ++m) {
         int iy, oy, ox;
         if constexpr (MODE == M_CONV) {
-            iy = y0 + 2 * wave + m;
+            iy = y0 + G::MT * wave + m;
             oy = iy;
             ox = ix;
         } else {
@@ -262,7 +263,7 @@ __device__ __forceinline__ void epilogue_t(const f32x16 (&acc)[G::MT][NT], const
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float t = acc[m][n][4 * g + j] + bias[j];
+                    float t = acc[m][n][4 * g + j] + (ADD_BIAS ? bias[j] : 0.f);
                     t = t > 0.f ? t : t * slope;
                     v[j] = fminf(t, hi);
                 }
@@ -323,7 +324,7 @@ __device__ __forceinline__ void epilogue_cl(const f32x16 (&acc)[G::MT][NT], cons
     for (int m = 0; m < G::MT; ++m) {
         int iy, oy;
         if constexpr (MODE == M_CONV) {
-            iy = y0 + 2 * wave + m;
+            iy = y0 + G::MT * wave + m;
             oy = iy;
         } else {
             iy = y0 + wave;
@@ -354,12 +355,12 @@ __device__ __forceinline__ void epilogue_cl(const f32x16 (&acc)[G::MT][NT], cons
     }
 }
 
-template <class G, int MODE, int NT, bool PL>
+template <class G, int MODE, int NT, bool PL, bool ADD_BIAS = true>
 __device__ __forceinline__ void epilogue(const f32x16 (&acc)[G::MT][NT], const ConvArgs& a, int pass, int b, int y0,
                                          int x0, int wave, int r, int h) {
     if constexpr (PL) {
-        if (a.out_f32) epilogue_t<G, MODE, NT, float>(acc, a, pass, b, y0, x0, wave, r, h);
-        else epilogue_t<G, MODE, NT, __bf16>(acc, a, pass, b, y0, x0, wave, r, h);
+        if (a.out_f32) epilogue_t<G, MODE, NT, float, ADD_BIAS>(acc, a, pass, b, y0, x0, wave, r, h);
+        else epilogue_t<G, MODE, NT, __bf16, ADD_BIAS>(acc, a, pass, b, y0, x0, wave, r, h);
     } else {
         if (a.out_f32) epilogue_cl<G, MODE, NT, float>(acc, a, pass, b, y0, x0, wave, r, h);
         else epilogue_cl<G, MODE, NT, __bf16>(acc, a, pass, b, y0, x0, wave, r, h);
@@ -461,11 +462,11 @@ struct EpiLds {
     static constexpr int WAVE_BYTES = 64 * ROW;
 };
 
-template <class G, int NT, typename OT>
+template <class G, int NT, typename OT, bool ADD_BIAS = true>
 __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[G::MT][NT], const ConvArgs& a, int b, int y0, int x0,
                                              int wave, int lane, unsigned char* smem) {
     using E = EpiLds<G, NT, OT>;
-    static_assert(G::MT == 2, "two 32-pixel rows per wave");
+    static_assert(G::MT % 2 == 0, "rows are transposed two at a time");
     const int r = lane & 31, h = lane >> 5;
     const int H = a.H, W = a.W;
     const int act = a.act;
@@ -481,9 +482,11 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[G::MT][NT], con
     OT* outp = reinterpret_cast<OT*>(a.out);
     const OT* resp = reinterpret_cast<const OT*>(a.res);
 
+#pragma unroll
+  for (int mg = 0; mg < G::MT / 2; ++mg) {   // 64 pixels (two tile rows) per round through the scratch
     // 1. bias + activation, column writes: lane = pixel r, 4 channels n*32 + 8g + 4h + (0..3) per store
 #pragma unroll
-    for (int m = 0; m < G::MT; ++m) {
+    for (int m = 2 * mg; m < 2 * mg + 2; ++m) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
 #pragma unroll
@@ -493,11 +496,11 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[G::MT][NT], con
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float t = acc[m][n][4 * g + j] + bias[j];
+                    float t = acc[m][n][4 * g + j] + (ADD_BIAS ? bias[j] : 0.f);
                     t = t > 0.f ? t : t * slope;
                     v[j] = fminf(t, hi);
                 }
-                unsigned char* dst = sc + (m * 32 + r) * E::ROW + cl * (int)sizeof(OT);
+                unsigned char* dst = sc + ((m & 1) * 32 + r) * E::ROW + cl * (int)sizeof(OT);
                 if constexpr (sizeof(OT) == 4) {
                     f32x4 o = {v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4*>(dst) = o;
@@ -511,7 +514,7 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[G::MT][NT], con
         }
     }
     // 2. row reads (same wave: LDS ops of one wave execute in order), residual add, coalesced stores
-    const int iy0 = y0 + 2 * wave;
+    const int iy0 = y0 + G::MT * wave + 2 * mg;
     const int p0 = prow;                                     // pixel of iteration 0; iteration k adds k*RPI
     const bool colok = cok;
 #pragma unroll
@@ -536,6 +539,148 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[G::MT][NT], con
                 }
             }
             *reinterpret_cast<u32x4*>(outp + opix * a.out_cs + co) = val;
+        }
+    }
+  }
+}
+
+// Per-thread staging plan: everything about "which 16-B vector of the halo tile is mine" that does
+// not depend on the tile or the chunk is computed ONCE per kernel, so staging a chunk costs one
+// global_load (uniform base + 32-bit lane offset) and one ds_write per vector instead of ~50 VALU
+// instructions of index arithmetic.
+template <class G>
+struct StagePlan {
+    unsigned goff[G::ITER];   // byte offset from the halo origin (tile row -1, column -1), chunk 0
+    unsigned loff[G::ITER];   // LDS byte offset in the (hi) tile; ~0u: no vector in this slot
+};
+
+template <class G, int PREC>
+__device__ __forceinline__ void plan_init(StagePlan<G>& pl, int tid, int W, int cin_p) {
+#pragma unroll
+    for (int it = 0; it < G::ITER; ++it) {
+        const int v = tid + it * 256;
+        const int p = v / G::VPP, part = v % G::VPP;
+        const int py = p / G::HCOLS, px = p - py * G::HCOLS;
+        pl.goff[it] = (unsigned)((py * W + px) * cin_p * G::ESZ + part * 16);
+        pl.loff[it] = v < G::NV ? (unsigned)(p * G::PS + part * (PREC == P_BF16X3 ? 8 : 16)) : ~0u;
+    }
+}
+
+template <class G>
+__device__ __forceinline__ unsigned tile_mask(int tid, int y0, int x0, int H, int W) {
+    unsigned mask = 0;
+#pragma unroll
+    for (int it = 0; it < G::ITER; ++it) {   // once per tile: recomputing beats holding ITER more registers
+        const int v = tid + it * 256;
+        const int p = v / G::VPP;
+        const int py = p / G::HCOLS, px = p - py * G::HCOLS;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool ok = v < G::NV && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        mask |= (ok ? 1u : 0u) << it;
+    }
+    return mask;
+}
+
+template <class G>
+__device__ __forceinline__ void stage_load_p(u32x4 (&regs)[G::ITER], const unsigned char* sbase, const StagePlan<G>& pl,
+                                             unsigned mask) {
+#pragma unroll
+    for (int it = 0; it < G::ITER; ++it) {
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if ((mask >> it) & 1u) val = *reinterpret_cast<const u32x4*>(sbase + pl.goff[it]);
+        regs[it] = val;
+    }
+}
+
+template <class G, int PREC>
+__device__ __forceinline__ void stage_store_p(const u32x4 (&regs)[G::ITER], unsigned char* smem, const StagePlan<G>& pl) {
+#pragma unroll
+    for (int it = 0; it < G::ITER; ++it) {
+        if (pl.loff[it] != ~0u) {
+            if constexpr (PREC == P_BF16X3) {
+                const f32x4 f = __builtin_bit_cast(f32x4, regs[it]);
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hi[e] = (__bf16)f[e];
+                    lo[e] = (__bf16)(f[e] - (float)hi[e]);
+                }
+                *reinterpret_cast<u32x2*>(smem + pl.loff[it]) = __builtin_bit_cast(u32x2, hi);
+                *reinterpret_cast<u32x2*>(smem + G::TILE_BYTES + pl.loff[it]) = __builtin_bit_cast(u32x2, lo);
+            } else {
+                *reinterpret_cast<u32x4*>(smem + pl.loff[it]) = regs[it];
+            }
+        }
+    }
+}
+
+// Fast epilogue for interior tiles whose channel block is stored whole: the accumulators already
+// hold the bias (they start from it), the activation is max(t, slope*t), and every address is a
+// uniform base plus one per-lane offset computed once.
+template <class G, int NT, typename OT>
+__device__ __forceinline__ void epilogue_lds_fast(const f32x16 (&acc)[G::MT][NT], const ConvArgs& a, int b, int y0, int x0,
+                                                  int wave, int lane, unsigned char* smem) {
+    using E = EpiLds<G, NT, OT>;
+    constexpr int SZ = (int)sizeof(OT);
+    const int r = lane & 31, h = lane >> 5;
+    const int act = a.act;
+    unsigned char* sc = smem + wave * E::WAVE_BYTES;
+    const int prow = lane / E::LPR, chunk = lane % E::LPR;
+    const int co = blockIdx.y * NT * 32 + chunk * (16 / SZ);
+    unsigned char* wr = sc + r * E::ROW + 4 * h * SZ;                 // + (m&1)*32*ROW + (n*32 + 8g)*SZ
+    const unsigned char* rd = sc + prow * E::ROW + chunk * 16;        // + k*RPI*ROW
+    const unsigned vo_out = (unsigned)((prow * a.out_cs + co) * SZ);
+    const unsigned vo_res = (unsigned)((prow * a.res_cs + co) * SZ);
+    unsigned char* outp = reinterpret_cast<unsigned char*>(a.out);
+    const unsigned char* resp = reinterpret_cast<const unsigned char*>(a.res);
+#pragma unroll
+    for (int mg = 0; mg < G::MT / 2; ++mg) {
+#pragma unroll
+        for (int m = 2 * mg; m < 2 * mg + 2; ++m) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float t = acc[m][n][4 * g + j];
+                        v[j] = act == A_RELU ? fmaxf(t, 0.f) : (act == A_LRELU ? fmaxf(t, 0.2f * t) : t);
+                    }
+                    unsigned char* dst = wr + (m & 1) * 32 * E::ROW + (n * 32 + 8 * g) * SZ;
+                    if constexpr (SZ == 4) {
+                        f32x4 o = {v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(dst) = o;
+                    } else {
+                        bf16x4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
+                        *reinterpret_cast<bf16x4*>(dst) = o;
+                    }
+                }
+            }
+        }
+        const size_t pix0 = ((size_t)b * a.H + y0 + G::MT * wave + 2 * mg) * a.W + x0;   // uniform
+        unsigned char* ob = outp + pix0 * a.out_cs * SZ;
+        const unsigned char* rb = resp ? resp + pix0 * a.res_cs * SZ : nullptr;
+#pragma unroll
+        for (int k = 0; k < E::NIT; ++k) {
+            const int prel = ((k * E::RPI) >> 5) * a.W + ((k * E::RPI) & 31);              // uniform
+            u32x4 val = *reinterpret_cast<const u32x4*>(rd + k * E::RPI * E::ROW);
+            if (rb) {
+                const u32x4 rr = *reinterpret_cast<const u32x4*>(rb + (size_t)prel * a.res_cs * SZ + vo_res);
+                if constexpr (SZ == 4) {
+                    f32x4 x = __builtin_bit_cast(f32x4, val), y = __builtin_bit_cast(f32x4, rr);
+                    x += y;
+                    val = __builtin_bit_cast(u32x4, x);
+                } else {
+                    bf16x8 x = __builtin_bit_cast(bf16x8, val), y = __builtin_bit_cast(bf16x8, rr);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = (__bf16)((float)x[j] + (float)y[j]);
+                    val = __builtin_bit_cast(u32x4, x);
+                }
+            }
+            *reinterpret_cast<u32x4*>(ob + (size_t)prel * a.out_cs * SZ + vo_out) = val;
         }
     }
 }
@@ -564,15 +709,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
     const size_t img_bytes = (size_t)H * W * a.cin_p * G::ESZ;
 
-    const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpack) + (size_t)blockIdx.y * a.wstride_cb + tid;
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.wpack) + (size_t)blockIdx.y * a.wstride_cb * 16;
     const unsigned char* in0 = reinterpret_cast<const unsigned char*>(a.in);
+    const unsigned tid16 = (unsigned)tid * 16u;
+    const size_t px_bytes = (size_t)a.cin_p * G::ESZ;
+
+    StagePlan<G> plan;
+    plan_init<G, PREC>(plan, tid, W, a.cin_p);
 
     u32x4 regs_a[G::ITER], regs_b[BITER];
-    auto load_w = [&](int c) {
+    auto load_w = [&](int c) {   // uniform base + lane offset: no per-load address arithmetic
+        const unsigned char* wb = wsrc + (size_t)c * BVEC * 16;
 #pragma unroll
         for (int it = 0; it < BITER; ++it) {
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (BVEC % 256 == 0 || tid + it * 256 < BVEC) v = wsrc[(size_t)c * BVEC + it * 256];
+            if (BVEC % 256 == 0 || tid + it * 256 < BVEC) v = *reinterpret_cast<const u32x4*>(wb + it * 4096 + tid16);
             regs_b[it] = v;
         }
     };
@@ -580,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
 #pragma unroll
         for (int it = 0; it < BITER; ++it)
             if (BVEC % 256 == 0 || tid + it * 256 < BVEC)
-                *reinterpret_cast<u32x4*>(smem_b + (size_t)(tid + it * 256) * 16) = regs_b[it];
+                *reinterpret_cast<u32x4*>(smem_b + it * 4096 + tid16) = regs_b[it];
     };
     struct TileXY {
         int b, y0, x0;
@@ -601,26 +752,48 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
     int t = blockIdx.x;
     if (t >= ntiles) return;
     TileXY cur = decode(t);
-    stage_load<G, PREC>(regs_a, in0 + cur.b * img_bytes, 0, a.cin_p, cur.y0, cur.x0, H, W, tid);
+    // halo origin of a tile (row y0-1, column x0-1; never dereferenced where it lies outside the image)
+    auto tile_base = [&](const TileXY& q) {
+        return in0 + q.b * img_bytes + ((ptrdiff_t)(q.y0 - 1) * W + (q.x0 - 1)) * (ptrdiff_t)px_bytes;
+    };
+    unsigned cur_mask = tile_mask<G>(tid, cur.y0, cur.x0, H, W);
+    stage_load_p<G>(regs_a, tile_base(cur), plan, cur_mask);
     load_w(0);
-    stage_store<G, PREC>(regs_a, smem, tid);
+    stage_store_p<G, PREC>(regs_a, smem, plan);
     store_w();
     __syncthreads();
 
     const unsigned char* bl = smem_b + lane * 16;
     for (;;) {
         f32x16 acc[G::MT][NT];
-        zero_acc<G, NT>(acc);
+#pragma unroll
+        for (int m = 0; m < G::MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+        // the accumulators start from the bias: lane (pixel r, half h) owns channels n*32 + 8g + 4h + (0..3)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + (blockIdx.y * NT + n) * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int m = 0; m < G::MT; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[m][n][4 * g + j] = bv[j];
+            }
         const int tn = t + gridDim.x;
         const bool have_next = tn < ntiles;
         const TileXY nxt = decode(have_next ? tn : t);
+        const unsigned nxt_mask = tile_mask<G>(tid, nxt.y0, nxt.x0, H, W);
         for (int c = 0; c < a.nchunk; ++c) {
             const bool last = c + 1 == a.nchunk;
             const bool pf = (!last || have_next) && !(a.dbg & 4);
             if (pf) {   // lands while this chunk's MFMAs run
-                const TileXY& q = last ? nxt : cur;
                 const int cn = last ? 0 : c + 1;
-                stage_load<G, PREC>(regs_a, in0 + q.b * img_bytes, cn, a.cin_p, q.y0, q.x0, H, W, tid);
+                stage_load_p<G>(regs_a, tile_base(last ? nxt : cur) + (size_t)cn * G::CKC * G::ESZ, plan,
+                                last ? nxt_mask : cur_mask);
                 load_w(cn);
             }
             if (!(a.dbg & 2)) {
@@ -667,7 +840,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
             }
             if (pf && !last) {
                 __syncthreads();   // every wave is done reading this chunk
-                stage_store<G, PREC>(regs_a, smem, tid);
+                stage_store_p<G, PREC>(regs_a, smem, plan);
                 store_w();
                 __syncthreads();
             }
@@ -683,26 +856,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
         } else if (via_lds) {
             if constexpr (PL) {
                 __syncthreads();   // the tile's last chunk has been read by every wave: LDS becomes scratch
-                if (a.out_f32) epilogue_lds<G, NT, float>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem);
-                else epilogue_lds<G, NT, __bf16>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem);
+                const bool interior = cur.y0 + G::TH <= H && cur.x0 + TW <= W &&
+                                      (int)(blockIdx.y + 1) * NT * 32 <= a.cout_store && a.act != A_CLIP01;
+                if (interior) {
+                    if (a.out_f32) epilogue_lds_fast<G, NT, float>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem);
+                    else epilogue_lds_fast<G, NT, __bf16>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem);
+                } else {
+                    if (a.out_f32) epilogue_lds<G, NT, float, false>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem);
+                    else epilogue_lds<G, NT, __bf16, false>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem);
+                }
             }
         } else {
-            epilogue<G, M_CONV, NT, PL>(acc, a, 0, cur.b, cur.y0, cur.x0, wave, r, h);
+            epilogue<G, M_CONV, NT, PL, false>(acc, a, 0, cur.b, cur.y0, cur.x0, wave, r, h);
         }
         if (!have_next) break;
         if (!(a.dbg & 4)) {
             __syncthreads();   // scratch reads / last chunk reads are done
-            stage_store<G, PREC>(regs_a, smem, tid);
+            stage_store_p<G, PREC>(regs_a, smem, plan);
             store_w();
             __syncthreads();
         }
         t = tn;
         cur = nxt;
+        cur_mask = nxt_mask;
     }
 }
 
-size_t conv_lds_bytes(int prec, int mode, int nt, int steps) {
-    const int th = mode == M_CONV ? 8 : 4, hb = mode == M_CONV ? 1 : 0;
+size_t conv_lds_bytes(int prec, int mode, int nt, int steps, int mt) {
+    const int th = mode == M_CONV ? 4 * mt : 4, hb = mode == M_CONV ? 1 : 0;
     const size_t tile = (size_t)(th + 1 + hb) * (TW + 1 + hb) * (32 * steps + 16);
     const size_t a = prec == P_BF16X3 ? 2 * tile : tile;
     if (mode == M_CONVT) return a;
@@ -724,17 +905,19 @@ static int num_cus() {
 }
 
 template <typename K>
-static hipError_t launch_k(K kernel, size_t lds, const ConvArgs& a, int ncb, hipStream_t s, bool& attr_done,
-                           bool persistent) {
+static hipError_t launch_k(K kernel, size_t lds, ConvArgs a, int th, int ncb, hipStream_t s, bool& attr_done,
+                           int wg_per_cu) {
     if (lds > 64 * 1024 && !attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + th - 1) / th;
     int gx = a.tiles_x * a.tiles_y * a.B;
-    if (persistent) {   // two workgroups per CU, every workgroup the same number of tiles (+-1)
-        const int maxwg = std::max(1, 2 * num_cus() / ncb);
+    if (wg_per_cu > 0) {   // persistent: every workgroup the same number of tiles (+-1)
+        const int maxwg = std::max(1, wg_per_cu * num_cus() / ncb);
         const int iters = (gx + maxwg - 1) / maxwg;
         gx = (gx + iters - 1) / iters;
     }
@@ -745,11 +928,12 @@ static hipError_t launch_k(K kernel, size_t lds, const ConvArgs& a, int ncb, hip
 template <int PREC, int MODE, int NT, int STEPS>
 static hipError_t launch_one(const ConvArgs& a, int ncb, hipStream_t s) {
     static bool attr_done = false;
-    const size_t lds = conv_lds_bytes(PREC, MODE, NT, STEPS);
     if constexpr (MODE == M_CONV) {
-        return launch_k(&conv3x3_lds_kernel<PREC, NT, STEPS, true>, lds, a, ncb, s, attr_done, true);
+        return launch_k(&conv3x3_lds_kernel<PREC, NT, STEPS, true>, conv_lds_bytes(PREC, MODE, NT, STEPS, 2), a, 8,
+                        ncb, s, attr_done, 2);
     } else {
-        return launch_k(&conv3x3_kernel<PREC, MODE, NT, STEPS>, lds, a, ncb, s, attr_done, false);
+        return launch_k(&conv3x3_kernel<PREC, MODE, NT, STEPS>, conv_lds_bytes(PREC, MODE, NT, STEPS, 1), a, 4, ncb,
+                        s, attr_done, 0);
     }
 }
 

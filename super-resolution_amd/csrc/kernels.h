@@ -45,7 +45,7 @@ __host__ __device__ constexpr int prec_maxsteps(int prec, int mode) {
 
 // host-side launchers (conv_mfma.hip)
 hipError_t launch_conv(int prec, int mode, int nt, int steps, const ConvArgs& a, int ncb, hipStream_t s);
-size_t conv_lds_bytes(int prec, int mode, int nt, int steps);
+size_t conv_lds_bytes(int prec, int mode, int nt, int steps, int mt);
 
 // element-wise / gather kernels (fused_ops.hip).  act_bf16: activations are bf16.
 hipError_t launch_fnet_input(const float* lr_t, const float* lr_tm1, void* out, int act_bf16,
