@@ -635,6 +635,18 @@ __device__ __forceinline__ void epilogue_lds_fast(const f32x16 (&acc)[G::MT][NT]
     const unsigned char* resp = reinterpret_cast<const unsigned char*>(a.res);
 #pragma unroll
     for (int mg = 0; mg < G::MT / 2; ++mg) {
+        const size_t pix0 = ((size_t)b * a.H + y0 + G::MT * wave + 2 * mg) * a.W + x0;   // uniform
+        unsigned char* ob = outp + pix0 * a.out_cs * SZ;
+        const unsigned char* rb = resp ? resp + pix0 * a.res_cs * SZ : nullptr;
+        // residual first: all loads of the 64-pixel block in flight while the transpose runs
+        u32x4 rr[E::NIT];
+        if (rb) {
+#pragma unroll
+            for (int k = 0; k < E::NIT; ++k) {
+                const int prel = ((k * E::RPI) >> 5) * a.W + ((k * E::RPI) & 31);          // uniform
+                rr[k] = *reinterpret_cast<const u32x4*>(rb + (size_t)prel * a.res_cs * SZ + vo_res);
+            }
+        }
 #pragma unroll
         for (int m = 2 * mg; m < 2 * mg + 2; ++m) {
 #pragma unroll
@@ -660,21 +672,17 @@ __device__ __forceinline__ void epilogue_lds_fast(const f32x16 (&acc)[G::MT][NT]
                 }
             }
         }
-        const size_t pix0 = ((size_t)b * a.H + y0 + G::MT * wave + 2 * mg) * a.W + x0;   // uniform
-        unsigned char* ob = outp + pix0 * a.out_cs * SZ;
-        const unsigned char* rb = resp ? resp + pix0 * a.res_cs * SZ : nullptr;
 #pragma unroll
         for (int k = 0; k < E::NIT; ++k) {
             const int prel = ((k * E::RPI) >> 5) * a.W + ((k * E::RPI) & 31);              // uniform
             u32x4 val = *reinterpret_cast<const u32x4*>(rd + k * E::RPI * E::ROW);
             if (rb) {
-                const u32x4 rr = *reinterpret_cast<const u32x4*>(rb + (size_t)prel * a.res_cs * SZ + vo_res);
                 if constexpr (SZ == 4) {
-                    f32x4 x = __builtin_bit_cast(f32x4, val), y = __builtin_bit_cast(f32x4, rr);
+                    f32x4 x = __builtin_bit_cast(f32x4, val), y = __builtin_bit_cast(f32x4, rr[k]);
                     x += y;
                     val = __builtin_bit_cast(u32x4, x);
                 } else {
-                    bf16x8 x = __builtin_bit_cast(bf16x8, val), y = __builtin_bit_cast(bf16x8, rr);
+                    bf16x8 x = __builtin_bit_cast(bf16x8, val), y = __builtin_bit_cast(bf16x8, rr[k]);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) x[j] = (__bf16)((float)x[j] + (float)y[j]);
                     val = __builtin_bit_cast(u32x4, x);
@@ -764,7 +772,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
     __syncthreads();
 
     const unsigned char* bl = smem_b + lane * 16;
+    const bool stamp = (a.dbg & 64) && a.stamps;
+    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0}, ntile = 0;
+#define SR_T() (stamp ? __builtin_readcyclecounter() : 0ull)
     for (;;) {
+        const unsigned long long t_tile = SR_T();
         f32x16 acc[G::MT][NT];
 #pragma unroll
         for (int m = 0; m < G::MT; ++m)
@@ -790,12 +802,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
         for (int c = 0; c < a.nchunk; ++c) {
             const bool last = c + 1 == a.nchunk;
             const bool pf = (!last || have_next) && !(a.dbg & 4);
+            unsigned long long t0 = SR_T();
             if (pf) {   // lands while this chunk's MFMAs run
                 const int cn = last ? 0 : c + 1;
                 stage_load_p<G>(regs_a, tile_base(last ? nxt : cur) + (size_t)cn * G::CKC * G::ESZ, plan,
                                 last ? nxt_mask : cur_mask);
                 load_w(cn);
             }
+            unsigned long long t1 = SR_T();
+            ts[0] += t1 - t0;
             if (!(a.dbg & 2)) {
                 u32x4 fa[2][G::MT][G::AV], fb[2][NB];
                 load_a<G, M_CONV>(fa[0], smem, 0, 0, wave, r, h);
@@ -838,13 +853,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            t0 = SR_T();
+            ts[1] += t0 - t1;
             if (pf && !last) {
                 __syncthreads();   // every wave is done reading this chunk
+                t1 = SR_T();
+                ts[2] += t1 - t0;
                 stage_store_p<G, PREC>(regs_a, smem, plan);
                 store_w();
+                t0 = SR_T();
+                ts[3] += t0 - t1;
                 __syncthreads();
+                t1 = SR_T();
+                ts[4] += t1 - t0;
             }
         }
+        unsigned long long t2 = SR_T();
         // wide, vector-aligned outputs leave through the LDS transpose; narrow ones (flow, image) directly
         const bool via_lds = PL && !(a.dbg & 8) && a.cout_store % 8 == 0 && a.out_cs % 8 == 0 &&
                              (!a.res || a.res_cs % 8 == 0) && a.act != A_TANH;
@@ -869,16 +893,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
         } else {
             epilogue<G, M_CONV, NT, PL, false>(acc, a, 0, cur.b, cur.y0, cur.x0, wave, r, h);
         }
-        if (!have_next) break;
-        if (!(a.dbg & 4)) {
+        unsigned long long t3 = SR_T();
+        ts[5] += t3 - t2;
+        if (have_next && !(a.dbg & 4)) {
             __syncthreads();   // scratch reads / last chunk reads are done
+            t2 = SR_T();
+            ts[2] += t2 - t3;
             stage_store_p<G, PREC>(regs_a, smem, plan);
             store_w();
+            t3 = SR_T();
+            ts[3] += t3 - t2;
             __syncthreads();
+            ts[4] += SR_T() - t3;
         }
+        ts[6] += SR_T() - t_tile;
+        ++ntile;
+        if (!have_next) break;
         t = tn;
         cur = nxt;
         cur_mask = nxt_mask;
+    }
+#undef SR_T
+    if (stamp && tid == 0) {
+        for (int i = 0; i < 7; ++i) atomicAdd(a.stamps + i, ts[i]);
+        atomicAdd(a.stamps + 7, ntile);
     }
 }
 

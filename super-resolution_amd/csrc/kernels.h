@@ -32,6 +32,7 @@ struct ConvArgs {
     int nchunk;            // number of input-channel chunks
     int wstride_cb;        // 16-byte vectors of wpack per output-channel block
     int dbg;               // ablation switches for tools/conv_bench.py (0 in production)
+    unsigned long long* stamps;   // diagnostic build only (dbg & 64): per-phase cycle sums, else nullptr
 };
 
 // steps per chunk / chunk geometry, shared by the packer and the kernel

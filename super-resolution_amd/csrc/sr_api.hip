@@ -21,6 +21,7 @@ namespace {
 
 thread_local std::string g_err;
 int g_conv_dbg = 0;   // ablation switches, set only by sr_bench_conv
+unsigned long long* g_conv_stamps = nullptr;
 
 struct HostTensor {
     std::string name;
@@ -289,6 +290,7 @@ int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, con
     a.nchunk = L.nchunk;
     a.wstride_cb = L.wstride_cb;
     a.dbg = g_conv_dbg;
+    a.stamps = g_conv_stamps;
     if (io.cout_store > L.ncb * L.nt * 32) return fail(c, SR_ERR_ARG, "%s: cout_store out of range", name);
     const double px = (double)B * io.H * io.W;
     const double esz_in = prec == P_BF16 ? 2 : 4, esz_out = io.out_f32 ? 4 : 2;
@@ -912,7 +914,7 @@ int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, in
     const int mode = transposed ? M_CONVT : M_CONV;
     ConvLayer L;
     plan_layer(L, dtype, mode, Cin, Cout);
-    struct Guard { ConvLayer& l; ~Guard() { free_layer(l); g_conv_dbg = 0; } } guard{L};
+    struct Guard { ConvLayer& l; ~Guard() { free_layer(l); g_conv_dbg = 0; g_conv_stamps = nullptr; } } guard{L};
     if (const char* e = getenv("SR_CONV_DBG")) g_conv_dbg = atoi(e);
     std::vector<float> w((size_t)9 * Cin * Cout), bias(Cout, 0.01f);
     uint32_t st = 12345u;
@@ -935,6 +937,10 @@ int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, in
     const ConvIO io{d_xp, H, W, d_out, cout_p, Cout, dtype == SR_BF16 ? 0 : 1, residual ? d_out : nullptr, cout_p, A_RELU};
     for (int i = 0; i < 3; ++i)
         if ((rc = run_conv(nullptr, dtype, nullptr, L, B, io, "bench_conv"))) return rc;
+    if (g_conv_dbg & 64) {
+        g_conv_stamps = (unsigned long long*)d.get(16 * 8);
+        HIPCHK(nullptr, hipMemset(g_conv_stamps, 0, 16 * 8));
+    }
     hipEvent_t e0, e1;
     HIPCHK(nullptr, hipEventCreate(&e0));
     HIPCHK(nullptr, hipEventCreate(&e1));
@@ -948,6 +954,14 @@ int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, in
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *ms_per_launch = ms / iters;
+    if (g_conv_stamps) {
+        unsigned long long hs[16];
+        HIPCHK(nullptr, hipMemcpy(hs, g_conv_stamps, sizeof hs, hipMemcpyDeviceToHost));
+        g_conv_stamps = nullptr;
+        static const char* nm[8] = {"fetch_issue", "mfma_loop", "barrier1", "lds_store", "barrier2", "epilogue", "tile_total", "n"};
+        double tot = (double)hs[6];
+        for (int i = 0; i < 7; ++i) fprintf(stderr, "  stamp %-12s %6.1f %%  (%.0f cycles / tile / wave0)\n", nm[i], 100.0 * hs[i] / tot, (double)hs[i] / (double)hs[7]);
+    }
     return SR_OK;
 }
 
