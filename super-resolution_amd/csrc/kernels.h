@@ -44,8 +44,12 @@ __host__ __device__ constexpr int prec_maxsteps(int prec, int mode) {
     return mode == M_CONV ? (prec == P_BF16X3 ? 1 : 2) : (prec == P_FP32 ? 8 : 4);
 }
 
-// host-side launchers (conv_mfma.hip)
+// taps-in-N kernel for <= 3 output channels (conv_tapsn.hip): channels per chunk = one 128-B line per pixel
+__host__ __device__ constexpr int tapsn_chunk(int prec) { return prec == P_BF16 ? 64 : 32; }
+
+// host-side launchers (conv_mfma.hip, conv_tapsn.hip)
 hipError_t launch_conv(int prec, int mode, int nt, int steps, const ConvArgs& a, int ncb, hipStream_t s);
+hipError_t launch_conv_tapsn(int prec, int nchunk, const ConvArgs& a, hipStream_t s);
 size_t conv_lds_bytes(int prec, int mode, int nt, int steps, int mt);
 
 // element-wise / gather kernels (fused_ops.hip).  act_bf16: activations are bf16.

@@ -33,6 +33,7 @@ struct ConvLayer {
     int mode = M_CONV;
     int cin = 0, cout = 0, cin_p = 0;
     int nt = 1, ncb = 1, steps = 1, nchunk = 1, wstride_cb = 0;
+    bool tapsn = false;   // <= 3 output channels: taps folded into N (conv_tapsn.hip)
     void* d_w = nullptr;
     float* d_bias = nullptr;
     double wbytes = 0;
@@ -123,6 +124,17 @@ void plan_layer(ConvLayer& L, int prec, int mode, int cin, int cout) {
     L.cin = cin;
     L.cout = cout;
     L.cin_p = round_up(cin, 16);
+    L.tapsn = false;
+    const int tck = tapsn_chunk(prec);
+    if (mode == M_CONV && cout <= 3 && L.cin_p % tck == 0 && L.cin_p / tck <= 2 && !getenv("SR_NO_TAPSN")) {
+        L.tapsn = true;
+        L.nchunk = L.cin_p / tck;
+        L.steps = tck / prec_ks(prec);
+        L.nt = 1;
+        L.ncb = 1;
+        L.wstride_cb = L.nchunk * L.steps * (prec == P_BF16X3 ? 2 : 1) * 64;
+        return;
+    }
     const int ks = prec_ks(prec);
     const int total_steps = L.cin_p / ks;
     int steps = prec_maxsteps(prec, mode);
@@ -141,6 +153,34 @@ std::vector<uint8_t> pack_weights(const ConvLayer& L, int prec, const float* w) 
     const int ckc = L.steps * ks;
     const int npass = L.mode == M_CONV ? 1 : 4;
     std::vector<uint8_t> out((size_t)L.ncb * L.wstride_cb * 16, 0);
+    if (L.tapsn) {
+        // [chunk][step][hi,lo][lane] x 16 B; lane (j, hh): GEMM column j = tap*3 + co (< 27), input
+        // channels chunk*CK + step*KS + (KS/2)*hh + e  -- the A fragment conv3x3_tapsn_kernel keeps in registers
+        const int ck = tapsn_chunk(prec);
+        for (int c = 0; c < L.nchunk; ++c)
+            for (int s = 0; s < L.steps; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int j = lane & 31, hh = lane >> 5;
+                    const int tap = j / 3, co = j % 3;
+                    const size_t vbase = (size_t)(c * L.steps + s) * bv * 64;
+                    for (int e = 0; e < half; ++e) {
+                        const int ci = c * ck + s * ks + half * hh + e;
+                        float v = 0.f;
+                        if (j < 27 && co < L.cout && ci < L.cin) v = w[((size_t)tap * L.cin + ci) * L.cout + co];
+                        if (prec == P_FP32) {
+                            memcpy(&out[(vbase + lane) * 16 + e * 4], &v, 4);
+                        } else {
+                            const uint16_t hi = f2bf(v);
+                            memcpy(&out[(vbase + lane) * 16 + e * 2], &hi, 2);
+                            if (prec == P_BF16X3) {
+                                const uint16_t lo = f2bf(v - bf2f(hi));
+                                memcpy(&out[(vbase + 64 + lane) * 16 + e * 2], &lo, 2);
+                            }
+                        }
+                    }
+                }
+        return out;
+    }
     auto W = [&](int ky, int kx, int ci, int co) -> float {
         if (ci >= L.cin || co >= L.cout) return 0.f;
         if (L.mode == M_CONV) return w[((size_t)(ky * 3 + kx) * L.cin + ci) * L.cout + co];
@@ -298,11 +338,15 @@ int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, con
     const double flops = px * 9.0 * L.cin * L.cout * 2.0;
     const double bytes = px * L.cin * esz_in + opx * io.cout_store * esz_out * (io.res ? 2 : 1) + L.wbytes;
     hipError_t e;
+    if (L.tapsn && (!io.out_f32 || io.cout_store > 3)) return fail(c, SR_ERR_ARG, "%s: taps-in-N conv needs an fp32 output of <= 3 channels", name);
+    auto launch = [&]() {
+        return L.tapsn ? launch_conv_tapsn(prec, L.nchunk, a, st) : launch_conv(prec, L.mode, L.nt, L.steps, a, L.ncb, st);
+    };
     if (c) {
         ProfScope ps(c, name, flops, bytes);
-        e = launch_conv(prec, L.mode, L.nt, L.steps, a, L.ncb, st);
+        e = launch();
     } else {
-        e = launch_conv(prec, L.mode, L.nt, L.steps, a, L.ncb, st);
+        e = launch();
     }
     if (e != hipSuccess) return fail(c, SR_ERR_HIP, "launch %s: %s", name, hipGetErrorString(e));
     return SR_OK;
@@ -924,17 +968,18 @@ int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, in
     DevBufs d;
     const size_t npix = (size_t)B * H * W, opix = mode == M_CONV ? npix : 4 * npix;
     const size_t es = dtype == SR_BF16 ? 2 : 4;
-    const int cout_p = round_up(Cout, 16);
+    const bool out_f32 = dtype != SR_BF16 || L.tapsn;   // image / flow outputs are always fp32
+    const int cout_p = L.tapsn ? Cout : round_up(Cout, 16);
     std::vector<float> x(npix * Cin);
     for (auto& v : x) v = rnd();
     float* d_x = (float*)d.get(npix * Cin * 4);
     void* d_xp = d.get(npix * L.cin_p * es);
-    void* d_out = d.get(opix * cout_p * es);
+    void* d_out = d.get(opix * cout_p * 4);
     if (!d_x || !d_xp || !d_out) return fail(nullptr, SR_ERR_HIP, "hipMalloc failed");
     HIPCHK(nullptr, hipMemcpy(d_x, x.data(), npix * Cin * 4, hipMemcpyHostToDevice));
     LAUNCHCHK(nullptr, "pad_channels", launch_pad_channels(d_x, d_xp, dtype == SR_BF16, (long)npix, Cin, L.cin_p, nullptr));
-    HIPCHK(nullptr, hipMemset(d_out, 0, opix * cout_p * es));
-    const ConvIO io{d_xp, H, W, d_out, cout_p, Cout, dtype == SR_BF16 ? 0 : 1, residual ? d_out : nullptr, cout_p, A_RELU};
+    HIPCHK(nullptr, hipMemset(d_out, 0, opix * cout_p * 4));
+    const ConvIO io{d_xp, H, W, d_out, cout_p, Cout, out_f32 ? 1 : 0, residual ? d_out : nullptr, cout_p, A_RELU};
     for (int i = 0; i < 3; ++i)
         if ((rc = run_conv(nullptr, dtype, nullptr, L, B, io, "bench_conv"))) return rc;
     if (g_conv_dbg & 64) {

@@ -73,6 +73,23 @@ def test_conv3x3_reduced_precision(sh, dtype, tol):
     assert np.abs(got - want).max() <= tol
 
 
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16x3", 2e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 19, 70, 64, 3), (1, 8, 40, 32, 2), (1, 33, 100, 32, 1),
+                                            (3, 8, 32, 64, 3), (1, 50, 31, 128, 3)])
+def test_conv3x3_few_outputs(sh, dtype, tol, B, H, W, Cin, Cout):
+    """<= 3 output channels run the taps-in-N kernel (conv_tapsn.hip) where the channel count fits
+    its 128-byte chunks, ragged tiles, several images and a residual included."""
+    x = rnd(20, B, H, W, Cin)
+    w = rnd(21, 3, 3, Cin, Cout, lo=-0.1, hi=0.1)
+    b = rnd(22, Cout, lo=-0.5, hi=0.5)
+    res = rnd(23, B, H, W, Cout)
+    want = rn.conv3x3_same(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+    got = sh.conv3x3(x, w, b, dtype=dtype)
+    assert np.abs(got - want).max() <= tol
+    got = sh.conv3x3(x, w, b, act="clip01", res=res, dtype=dtype)
+    assert np.abs(got - (rn.clip01(want) + res)).max() <= tol
+
+
 CONVT_CASES = [(1, 8, 32, 64, 64), (2, 4, 8, 16, 64), (1, 5, 7, 3, 5), (1, 16, 40, 64, 64), (1, 1, 1, 2, 3)]
 
 
