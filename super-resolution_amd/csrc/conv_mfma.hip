@@ -117,7 +117,7 @@ __host__ __device__ constexpr int pass_tap(int mode, int pass, int t) {
 
 template <class G, int PREC>
 __device__ __forceinline__ void stage_load(u32x4 (&regs)[G::ITER], const unsigned char* inb, int c, int cin_p,
-                                           int y0, int x0, int H, int W, int tid) {
+                                           int y0, int x0, int H, int W, int tid, int planar = 0) {
 #pragma unroll
     for (int it = 0; it < G::ITER; ++it) {
         const int v = tid + it * 256;
@@ -126,7 +126,11 @@ __device__ __forceinline__ void stage_load(u32x4 (&regs)[G::ITER], const unsigne
         const int gy = y0 - 1 + py, gx = x0 - 1 + px;
         u32x4 val = {0u, 0u, 0u, 0u};
         if (v < G::NV && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const size_t off = (((size_t)gy * W + gx) * cin_p + (size_t)c * G::CKC) * G::ESZ + part * 16;
+            size_t off = (((size_t)gy * W + gx) * cin_p + (size_t)c * G::CKC) * G::ESZ + part * 16;
+            if (planar) {   // planes of 64 B per pixel (kernels.h): 16-B piece q of the pixel's channel row
+                const int q = c * G::VPP + part;
+                off = (size_t)(q >> 2) * H * W * 64 + ((size_t)gy * W + gx) * 64 + (q & 3) * 16;
+            }
             val = *reinterpret_cast<const u32x4*>(inb + off);
         }
         regs[it] = val;
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
     for (int i = 0; i < G::PF; ++i) load_b<G>(ring[i], wbase, i, last_step);
 
     u32x4 regs[G::ITER];
-    stage_load<G, PREC>(regs, inb, 0, a.cin_p, y0, x0, H, W, tid);
+    stage_load<G, PREC>(regs, inb, 0, a.cin_p, y0, x0, H, W, tid, a.in_planar);
     stage_store<G, PREC>(regs, smem, tid);
     __syncthreads();
 
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
         constexpr int NSEG = 9 * STEPS;
         for (int c = 0; c < a.nchunk; ++c) {
             const bool more = c + 1 < a.nchunk;
-            if (more) stage_load<G, PREC>(regs, inb, c + 1, a.cin_p, y0, x0, H, W, tid);   // lands during the MFMAs
+            if (more) stage_load<G, PREC>(regs, inb, c + 1, a.cin_p, y0, x0, H, W, tid, a.in_planar);   // lands during the MFMAs
             run_segment<G, PREC, MODE, NT, STEPS, 0>(acc, ring, smem, wbase, c * NSEG, last_step, wave, r, h);
             if (more) {
                 __syncthreads();   // every wave is done reading chunk c
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
         int gstep = 0;
         auto restage = [&](int c) {
             __syncthreads();
-            stage_load<G, PREC>(regs, inb, c, a.cin_p, y0, x0, H, W, tid);
+            stage_load<G, PREC>(regs, inb, c, a.cin_p, y0, x0, H, W, tid, a.in_planar);
             stage_store<G, PREC>(regs, smem, tid);
             __syncthreads();
         };
@@ -479,8 +483,14 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[G::MT][NT], con
     constexpr int EPV = 16 / (int)sizeof(OT);               // channels per 16-B vector
     const int co = cbase + chunk * EPV;
     const bool cok = co < a.cout_store;
-    OT* outp = reinterpret_cast<OT*>(a.out);
-    const OT* resp = reinterpret_cast<const OT*>(a.res);
+    // byte addressing: image base + pixel * pixel stride + this lane's 16-B piece of the channel row
+    constexpr int SZ = (int)sizeof(OT);
+    const unsigned cob = (unsigned)(co * SZ);
+    const size_t plane = (size_t)H * W * 64;
+    const size_t pxs_o = a.out_planar ? 64 : (size_t)a.out_cs * SZ, pxs_r = a.out_planar ? 64 : (size_t)a.res_cs * SZ;
+    const size_t lo = a.out_planar ? (size_t)(cob >> 6) * plane + (cob & 63) : cob;
+    unsigned char* outp = reinterpret_cast<unsigned char*>(a.out) + (size_t)b * H * W * a.out_cs * SZ + lo;
+    const unsigned char* resp = a.res ? reinterpret_cast<const unsigned char*>(a.res) + (size_t)b * H * W * a.res_cs * SZ + lo : nullptr;
 
 #pragma unroll
   for (int mg = 0; mg < G::MT / 2; ++mg) {   // 64 pixels (two tile rows) per round through the scratch
@@ -522,11 +532,11 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[G::MT][NT], con
         const int p = p0 + k * E::RPI;                       // 0..63: m = p >> 5, px = p & 31
         const int iy = iy0 + (p >> 5), ix = x0 + (p & 31);
         const bool ok = colok && iy < H && ix < W;
-        const size_t opix = ((size_t)b * H + iy) * W + ix;
+        const size_t opix = (size_t)iy * W + ix;
         u32x4 val = *reinterpret_cast<const u32x4*>(sc + p * E::ROW + chunk * 16);
         if (ok) {
             if (resp) {
-                const u32x4 rr = *reinterpret_cast<const u32x4*>(resp + opix * a.res_cs + co);
+                const u32x4 rr = *reinterpret_cast<const u32x4*>(resp + opix * pxs_r);
                 if constexpr (sizeof(OT) == 4) {
                     f32x4 x = __builtin_bit_cast(f32x4, val), y = __builtin_bit_cast(f32x4, rr);
                     x += y;
@@ -538,7 +548,7 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[G::MT][NT], con
                     val = __builtin_bit_cast(u32x4, x);
                 }
             }
-            *reinterpret_cast<u32x4*>(outp + opix * a.out_cs + co) = val;
+            *reinterpret_cast<u32x4*>(outp + opix * pxs_o) = val;
         }
     }
   }
@@ -555,13 +565,13 @@ struct StagePlan {
 };
 
 template <class G, int PREC>
-__device__ __forceinline__ void plan_init(StagePlan<G>& pl, int tid, int W, int cin_p) {
+__device__ __forceinline__ void plan_init(StagePlan<G>& pl, int tid, int W, int px_bytes) {
 #pragma unroll
     for (int it = 0; it < G::ITER; ++it) {
         const int v = tid + it * 256;
         const int p = v / G::VPP, part = v % G::VPP;
         const int py = p / G::HCOLS, px = p - py * G::HCOLS;
-        pl.goff[it] = (unsigned)((py * W + px) * cin_p * G::ESZ + part * 16);
+        pl.goff[it] = (unsigned)((py * W + px) * px_bytes + part * 16);
         pl.loff[it] = v < G::NV ? (unsigned)(p * G::PS + part * (PREC == P_BF16X3 ? 8 : 16)) : ~0u;
     }
 }
@@ -629,22 +639,26 @@ __device__ __forceinline__ void epilogue_lds_fast(const f32x16 (&acc)[G::MT][NT]
     const int co = blockIdx.y * NT * 32 + chunk * (16 / SZ);
     unsigned char* wr = sc + r * E::ROW + 4 * h * SZ;                 // + (m&1)*32*ROW + (n*32 + 8g)*SZ
     const unsigned char* rd = sc + prow * E::ROW + chunk * 16;        // + k*RPI*ROW
-    const unsigned vo_out = (unsigned)((prow * a.out_cs + co) * SZ);
-    const unsigned vo_res = (unsigned)((prow * a.res_cs + co) * SZ);
-    unsigned char* outp = reinterpret_cast<unsigned char*>(a.out);
-    const unsigned char* resp = reinterpret_cast<const unsigned char*>(a.res);
+    const unsigned cob = (unsigned)(co * SZ);                        // this lane's 16-B piece of the channel row
+    const unsigned plane = (unsigned)(a.H * a.W * 64);
+    const unsigned pxs_o = a.out_planar ? 64u : (unsigned)(a.out_cs * SZ), pxs_r = a.out_planar ? 64u : (unsigned)(a.res_cs * SZ);
+    const unsigned lo = a.out_planar ? (cob >> 6) * plane + (cob & 63) : cob;
+    const unsigned vo_out = prow * pxs_o + lo;
+    const unsigned vo_res = prow * pxs_r + lo;
+    unsigned char* outp = reinterpret_cast<unsigned char*>(a.out) + (size_t)b * a.H * a.W * a.out_cs * SZ;
+    const unsigned char* resp = a.res ? reinterpret_cast<const unsigned char*>(a.res) + (size_t)b * a.H * a.W * a.res_cs * SZ : nullptr;
 #pragma unroll
     for (int mg = 0; mg < G::MT / 2; ++mg) {
-        const size_t pix0 = ((size_t)b * a.H + y0 + G::MT * wave + 2 * mg) * a.W + x0;   // uniform
-        unsigned char* ob = outp + pix0 * a.out_cs * SZ;
-        const unsigned char* rb = resp ? resp + pix0 * a.res_cs * SZ : nullptr;
+        const size_t pix0 = (size_t)(y0 + G::MT * wave + 2 * mg) * a.W + x0;   // uniform, within the image
+        unsigned char* ob = outp + pix0 * pxs_o;
+        const unsigned char* rb = resp ? resp + pix0 * pxs_r : nullptr;
         // residual first: all loads of the 64-pixel block in flight while the transpose runs
         u32x4 rr[E::NIT];
         if (rb) {
 #pragma unroll
             for (int k = 0; k < E::NIT; ++k) {
                 const int prel = ((k * E::RPI) >> 5) * a.W + ((k * E::RPI) & 31);          // uniform
-                rr[k] = *reinterpret_cast<const u32x4*>(rb + (size_t)prel * a.res_cs * SZ + vo_res);
+                rr[k] = *reinterpret_cast<const u32x4*>(rb + (size_t)prel * pxs_r + vo_res);
             }
         }
 #pragma unroll
@@ -688,7 +702,7 @@ __device__ __forceinline__ void epilogue_lds_fast(const f32x16 (&acc)[G::MT][NT]
                     val = __builtin_bit_cast(u32x4, x);
                 }
             }
-            *reinterpret_cast<u32x4*>(ob + (size_t)prel * a.out_cs * SZ + vo_out) = val;
+            *reinterpret_cast<u32x4*>(ob + (size_t)prel * pxs_o + vo_out) = val;
         }
     }
 }
@@ -720,10 +734,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.wpack) + (size_t)blockIdx.y * a.wstride_cb * 16;
     const unsigned char* in0 = reinterpret_cast<const unsigned char*>(a.in);
     const unsigned tid16 = (unsigned)tid * 16u;
-    const size_t px_bytes = (size_t)a.cin_p * G::ESZ;
+    const size_t px_bytes = a.in_planar ? 64 : (size_t)a.cin_p * G::ESZ;
+    const size_t chunk_bytes = a.in_planar ? (size_t)H * W * 64 : (size_t)G::CKC * G::ESZ;
 
     StagePlan<G> plan;
-    plan_init<G, PREC>(plan, tid, W, a.cin_p);
+    plan_init<G, PREC>(plan, tid, W, (int)px_bytes);
 
     u32x4 regs_a[G::ITER], regs_b[BITER];
     auto load_w = [&](int c) {   // uniform base + lane offset: no per-load address arithmetic
@@ -805,7 +820,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
             unsigned long long t0 = SR_T();
             if (pf) {   // lands while this chunk's MFMAs run
                 const int cn = last ? 0 : c + 1;
-                stage_load_p<G>(regs_a, tile_base(last ? nxt : cur) + (size_t)cn * G::CKC * G::ESZ, plan,
+                stage_load_p<G>(regs_a, tile_base(last ? nxt : cur) + (size_t)cn * chunk_bytes, plan,
                                 last ? nxt_mask : cur_mask);
                 load_w(cn);
             }

@@ -31,6 +31,11 @@ struct ConvArgs {
     int tiles_x, tiles_y;
     int nchunk;            // number of input-channel chunks
     int wstride_cb;        // 16-byte vectors of wpack per output-channel block
+    // planar activations: [B][planes][H][W][64 bytes] instead of [B][H][W][channels]; a plane holds
+    // one conv chunk (16 fp32 / 32 bf16 channels), so a chunk's halo row is contiguous full 128-B
+    // lines instead of a 64-byte half of every pixel's lines.  Image stride is the same either way.
+    int in_planar;         // input is planar (needs 64-byte chunks: steps == prec_maxsteps)
+    int out_planar;        // output and residual are planar (cout_store a multiple of 64 bytes)
     int dbg;               // ablation switches for tools/conv_bench.py (0 in production)
     unsigned long long* stamps;   // diagnostic build only (dbg & 64): per-phase cycle sums, else nullptr
 };

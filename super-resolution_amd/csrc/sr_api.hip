@@ -81,6 +81,7 @@ struct sr_ctx {
     bool clip_active = false;
     int clip_B = 0, cur = 0;
     int trunk_sub = 0;   // clips per trunk sub-batch (0 = whole batch)
+    int planar_trunk = 1;   // SRNet trunk activations (sx, sy) in 64-byte planes; SR_NO_PLANAR=1 disables
     // profiling
     bool prof_on = false;
     std::vector<ProfEntry> prof;
@@ -306,6 +307,7 @@ struct ConvIO {
     const void* res;
     int res_cs;
     int act;
+    int in_planar = 0, out_planar = 0;   // kernels.h: planes of 64 B per pixel
 };
 
 int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, const ConvIO& io, const char* name) {
@@ -324,6 +326,13 @@ int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, con
     a.cout_store = io.cout_store;
     a.out_f32 = io.out_f32;
     a.act = io.act;
+    a.in_planar = io.in_planar;
+    a.out_planar = io.out_planar;
+    if (io.in_planar && (L.tapsn || L.steps != prec_maxsteps(prec, L.mode) || (L.mode == M_CONVT && L.nchunk != 1)))
+        return fail(c, SR_ERR_ARG, "%s: planar input needs 64-byte chunks", name);
+    if (io.out_planar && (L.tapsn || L.mode != M_CONV || (io.cout_store * (io.out_f32 ? 4 : 2)) % 64 || io.cout_store != io.out_cs ||
+                          (io.res && io.res_cs != io.out_cs) || io.act == A_TANH))
+        return fail(c, SR_ERR_ARG, "%s: planar output needs whole 64-byte planes", name);
     const int th = L.mode == M_CONV ? 8 : 4;
     a.tiles_x = (io.W + TW - 1) / TW;
     a.tiles_y = (io.H + th - 1) / th;
@@ -460,18 +469,19 @@ int run_srnet(sr_ctx* c, int B, float* d_out) {
         unsigned char* s_in = (unsigned char*)c->buf["s_in"] + off;
         unsigned char* sx = (unsigned char*)c->buf["sx"] + off;
         unsigned char* sy = (unsigned char*)c->buf["sy"] + off;
-        int rc = run_conv(c, P, st, c->srnet[0], nb, {s_in, H, W, sx, 64, 64, af, nullptr, 0, A_RELU}, "srnet.head");
+        const int pl = c->planar_trunk;   // trunk activations in 64-byte planes (kernels.h)
+        int rc = run_conv(c, P, st, c->srnet[0], nb, {s_in, H, W, sx, 64, 64, af, nullptr, 0, A_RELU, 0, pl}, "srnet.head");
         if (rc) return rc;
         for (int r = 0; r < 10; ++r) {
-            rc = run_conv(c, P, st, c->srnet[1 + 2 * r], nb, {sx, H, W, sy, 64, 64, af, nullptr, 0, A_RELU}, "srnet.res");
+            rc = run_conv(c, P, st, c->srnet[1 + 2 * r], nb, {sx, H, W, sy, 64, 64, af, nullptr, 0, A_RELU, pl, pl}, "srnet.res");
             if (rc) return rc;
             // x = x + conv(y): each thread reads then writes its own element, in place is safe
-            rc = run_conv(c, P, st, c->srnet[2 + 2 * r], nb, {sy, H, W, sx, 64, 64, af, sx, 64, A_NONE}, "srnet.res");
+            rc = run_conv(c, P, st, c->srnet[2 + 2 * r], nb, {sy, H, W, sx, 64, 64, af, sx, 64, A_NONE, pl, pl}, "srnet.res");
             if (rc) return rc;
         }
     }
     auto b = [&](const char* n) { return c->buf[n]; };
-    int rc = run_conv(c, P, st, c->srnet[21], B, {b("sx"), H, W, b("up1"), 64, 64, af, nullptr, 0, A_RELU}, "srnet.up1");
+    int rc = run_conv(c, P, st, c->srnet[21], B, {b("sx"), H, W, b("up1"), 64, 64, af, nullptr, 0, A_RELU, c->planar_trunk, 0}, "srnet.up1");
     if (rc) return rc;
     rc = run_conv(c, P, st, c->srnet[22], B, {b("up1"), 2 * H, 2 * W, b("up2"), 64, 64, af, nullptr, 0, A_RELU}, "srnet.up2");
     if (rc) return rc;
@@ -544,6 +554,7 @@ int sr_create(sr_ctx** out, int device, int h, int w, int ch, int scale, int max
     c->prec = dtype;
     c->model = model;
     if (const char* e = getenv("SR_TRUNK_SUB")) c->trunk_sub = atoi(e);
+    if (getenv("SR_NO_PLANAR")) c->planar_trunk = 0;
     int rc = SR_OK;
     auto bail = [&](int code) {
         g_err = c->err;
