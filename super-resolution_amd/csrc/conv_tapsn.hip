@@ -131,12 +131,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tapsn_kernel(const ConvArgs a)
     struct TileXY {
         int b, y0, x0;
     };
+    // tile order: 8x8-tile super tiles, row major inside, so that the ~64 workgroups of an XCD work on
+    // a compact block at any time and halo rows / columns come from L2 instead of HBM a second time
+    const int per_img = a.tiles_x * a.tiles_y;
+    const int nsx = (a.tiles_x + 7) >> 3;
     auto decode = [&](int tt) {
         TileXY q;
-        q.x0 = (tt % a.tiles_x) * TW;
-        tt /= a.tiles_x;
-        q.y0 = (tt % a.tiles_y) * T::TH;
-        q.b = tt / a.tiles_y;
+        q.b = tt / per_img;
+        int rem = tt - q.b * per_img;
+        const int sy = rem / (8 * a.tiles_x);
+        rem -= sy * 8 * a.tiles_x;
+        const int rows = min(8, a.tiles_y - 8 * sy);
+        const int sx = min(rem / (rows * 8), nsx - 1);
+        rem -= sx * rows * 8;
+        const int cols = min(8, a.tiles_x - 8 * sx);
+        const int iy = rem / cols, ix = rem - iy * cols;
+        q.y0 = (8 * sy + iy) * T::TH;
+        q.x0 = (8 * sx + ix) * TW;
         return q;
     };
     const unsigned char* in0 = reinterpret_cast<const unsigned char*>(a.in);
