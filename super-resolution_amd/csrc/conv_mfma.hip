@@ -371,6 +371,80 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[G::MT][NT], const C
     }
 }
 
+// Transposed conv + tap projection of the FOLLOWING 3x3 conv with <= 3 output channels (SRNet:
+// conv2d_transpose_2 -> ReLU -> conv2d_36, reference layers.py:74-75).  Instead of storing the 64
+// activated channels of an output pixel (256 B) this epilogue multiplies them, still in registers,
+// with the next layer's weights arranged as a 64 x 27 matrix (column = tap*3 + channel) and stores the
+// 27 partial sums P[pixel][tap, co] (one 128-B line); tap_gather_kernel (conv_tapsn.hip) then adds the
+// nine shifted P planes.  The accumulator layout IS the MFMA B-operand layout up to a permutation of K
+// (lane (pixel r, half h) holds channels n*32 + 8g + 4h + j), which the host applies to the packed
+// projection weights, so no data moves between the two MFMA stages.
+template <class G, int PREC>
+__device__ __forceinline__ void epilogue_proj(const f32x16 (&acc)[G::MT][2], const ConvArgs& a, int pass, int b, int y0,
+                                              int x0, int wave, int lane) {
+    static_assert(G::MT == 1, "transposed-conv tiles have one row per wave");
+    const int r = lane & 31, h = lane >> 5;
+    const int H = a.H, W = a.W;
+    const float slope = a.act == A_RELU ? 0.f : (a.act == A_LRELU ? 0.2f : 1.f);
+    const int iy = y0 + wave, ix = x0 + r;
+    const u32x4* pw = reinterpret_cast<const u32x4*>(a.proj_w) + lane;
+    f32x16 p;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) p[i] = 0.f;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int g = 2 * s + q;
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + n * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = acc[0][n][4 * g + j] + bias[j];
+                    v[4 * q + j] = fmaxf(t, slope * t);
+                }
+            }
+            const int kidx = n * 2 + s;
+            if constexpr (PREC == P_FP32) {
+                const f32x4 w0 = __builtin_bit_cast(f32x4, pw[(kidx * 2 + 0) * 64]);
+                const f32x4 w1 = __builtin_bit_cast(f32x4, pw[(kidx * 2 + 1) * 64]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], v[e], p, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], v[4 + e], p, 0, 0, 0);
+            } else {
+                bf16x8 xh, xl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[e] = (__bf16)v[e];
+                    xl[e] = (__bf16)(v[e] - (float)xh[e]);
+                }
+                if constexpr (PREC == P_BF16X3) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, pw[(kidx * 2 + 0) * 64]);
+                    const bf16x8 wl = __builtin_bit_cast(bf16x8, pw[(kidx * 2 + 1) * 64]);
+                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, p, 0, 0, 0);
+                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, p, 0, 0, 0);
+                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, p, 0, 0, 0);
+                } else {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, pw[kidx * 64]);
+                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, p, 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (iy < H && ix < W) {
+        const int oy = 2 * iy + (pass >> 1), ox = 2 * ix + (pass & 1);
+        float* op = reinterpret_cast<float*>(a.out) + (((size_t)b * 2 * H + oy) * 2 * W + ox) * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o = {p[4 * g], p[4 * g + 1], p[4 * g + 2], p[4 * g + 3]};
+            *reinterpret_cast<f32x4*>(op + 8 * g) = o;
+        }
+    }
+}
+
 template <class G, int NT>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[G::MT][NT]) {
 #pragma unroll
@@ -444,7 +518,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
             run_segment<G, PREC, MODE, NT, STEPS, P>(acc, ring, smem, wbase, gstep, last_step, wave, r, h);     \
             gstep += pass_ntaps(MODE, P) * STEPS;                                                               \
         }                                                                                                       \
-        epilogue<G, MODE, NT, true>(acc, a, P, b, y0, x0, wave, r, h);
+        if constexpr (NT == 2) {                                                                                \
+            if (a.proj_w) epilogue_proj<G, PREC>(acc, a, P, b, y0, x0, wave, lane);                             \
+            else epilogue<G, MODE, NT, true>(acc, a, P, b, y0, x0, wave, r, h);                                 \
+        } else {                                                                                                \
+            epilogue<G, MODE, NT, true>(acc, a, P, b, y0, x0, wave, r, h);                                      \
+        }
         SR_PASS(0)
         SR_PASS(1)
         SR_PASS(2)

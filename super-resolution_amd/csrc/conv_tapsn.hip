@@ -284,6 +284,126 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tapsn_kernel(const ConvArgs a)
     }
 }
 
+// Second half of the fused transposed-conv + tap projection (conv_mfma.hip epilogue_proj): the input
+// already holds P[pixel][tap*3 + co] (one 128-B line per pixel); stage the 10x34 halo tile of P in LDS
+// and add the nine shifted planes.  Pure streaming: 128 B in, 4*cout B out per pixel.
+__global__ __launch_bounds__(256, 2) void tap_gather_kernel(const ConvArgs a) {
+    using T = TG<P_FP32>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W;
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    const int per_xcd = (ntiles + 7) / 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int t_end = min(ntiles, (xcd + 1) * per_xcd);
+    int t = xcd * per_xcd + slot;
+    if (t >= t_end) return;
+
+    unsigned goff[T::ITER], loff[T::ITER];
+#pragma unroll
+    for (int it = 0; it < T::ITER; ++it) {
+        const int v = tid + it * 256;
+        const int p = v >> 3, part = v & 7;
+        const int py = p / T::HCOLS, px = p - py * T::HCOLS;
+        goff[it] = (unsigned)((py * W + px) * 128 + part * 16);
+        loff[it] = v < T::NV ? (unsigned)((p * T::PROW + part * 4) * 4) : ~0u;
+    }
+    auto tile_mask = [&](int y0, int x0) {
+        unsigned m = 0;
+#pragma unroll
+        for (int it = 0; it < T::ITER; ++it) {
+            const int v = tid + it * 256;
+            const int p = v >> 3;
+            const int py = p / T::HCOLS, px = p - py * T::HCOLS;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            m |= ((v < T::NV && gy >= 0 && gy < H && gx >= 0 && gx < W) ? 1u : 0u) << it;
+        }
+        return m;
+    };
+    struct TileXY {
+        int b, y0, x0;
+    };
+    const int per_img = a.tiles_x * a.tiles_y;
+    const int nsx = (a.tiles_x + 7) >> 3;
+    auto decode = [&](int tt) {   // 8x8 super tiles, as in conv3x3_tapsn_kernel
+        TileXY q;
+        q.b = tt / per_img;
+        int rem = tt - q.b * per_img;
+        const int sy = rem / (8 * a.tiles_x);
+        rem -= sy * 8 * a.tiles_x;
+        const int rows = min(8, a.tiles_y - 8 * sy);
+        const int sx = min(rem / (rows * 8), nsx - 1);
+        rem -= sx * rows * 8;
+        const int cols = min(8, a.tiles_x - 8 * sx);
+        const int iy = rem / cols, ix = rem - iy * cols;
+        q.y0 = (8 * sy + iy) * T::TH;
+        q.x0 = (8 * sx + ix) * TW;
+        return q;
+    };
+    const unsigned char* in0 = reinterpret_cast<const unsigned char*>(a.in);
+    const size_t img_bytes = (size_t)H * W * 128;
+    auto tile_base = [&](const TileXY& q) {
+        return in0 + q.b * img_bytes + ((ptrdiff_t)(q.y0 - 1) * W + (q.x0 - 1)) * (ptrdiff_t)128;
+    };
+    f32x4 regs[T::ITER];
+    auto fetch = [&](const unsigned char* base, unsigned mask) {
+#pragma unroll
+        for (int it = 0; it < T::ITER; ++it) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((mask >> it) & 1u) v = *reinterpret_cast<const f32x4*>(base + goff[it]);
+            regs[it] = v;
+        }
+    };
+    TileXY cur = decode(t);
+    fetch(tile_base(cur), tile_mask(cur.y0, cur.x0));
+    float bias[3];
+#pragma unroll
+    for (int co = 0; co < 3; ++co) bias[co] = a.bias[co];
+    float* P = reinterpret_cast<float*>(smem);
+    const int oy = tid >> 5, ox = tid & 31;
+    for (;;) {
+        const int tn = t + nslot;
+        const bool have_next = tn < t_end;
+        const TileXY nxt = decode(have_next ? tn : t);
+#pragma unroll
+        for (int it = 0; it < T::ITER; ++it) {
+            if (loff[it] != ~0u) {
+                float* d = reinterpret_cast<float*>(smem + loff[it]);   // 33-float rows: scalar stores
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = regs[it][e];
+            }
+        }
+        __syncthreads();
+        if (have_next) fetch(tile_base(nxt), tile_mask(nxt.y0, nxt.x0));
+        float o[3] = {bias[0], bias[1], bias[2]};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float* pp = P + ((oy + ky) * T::HCOLS + ox + kx) * T::PROW + (ky * 3 + kx) * 3;
+#pragma unroll
+                for (int co = 0; co < 3; ++co) o[co] += pp[co];
+            }
+        const int gy = cur.y0 + oy, gx = cur.x0 + ox;
+        if (gy < H && gx < W) {
+            const size_t pix = ((size_t)cur.b * H + gy) * W + gx;
+            float* op = reinterpret_cast<float*>(a.out) + pix * a.out_cs;
+            const float* rp = a.res ? reinterpret_cast<const float*>(a.res) + pix * a.res_cs : nullptr;
+#pragma unroll
+            for (int co = 0; co < 3; ++co)
+                if (co < a.cout_store) {
+                    float v = act_t(o[co], a.act);
+                    if (rp) v += rp[co];
+                    op[co] = v;
+                }
+        }
+        if (!have_next) break;
+        __syncthreads();
+        t = tn;
+        cur = nxt;
+    }
+}
+
 int cu_count() {
     static int n = 0;
     if (!n) {
@@ -318,6 +438,19 @@ hipError_t launch_tapsn(const ConvArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+hipError_t launch_tap_gather(const ConvArgs& a, hipStream_t s) {
+    using T = TG<P_FP32>;
+    if (!a.out_f32 || a.cout_store > 3) return hipErrorInvalidValue;
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    if (ntiles <= 0) return hipSuccess;
+    const int per_xcd = (ntiles + 7) / 8;
+    const int max_slots = std::max(1, 2 * cu_count() / 8);
+    const int rounds = (per_xcd + max_slots - 1) / max_slots;
+    const int slots = (per_xcd + rounds - 1) / rounds;
+    hipLaunchKernelGGL(tap_gather_kernel, dim3(8 * slots), dim3(256), T::P_BYTES, s, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_conv_tapsn(int prec, int nchunk, const ConvArgs& a, hipStream_t s) {
     if (nchunk != 1 && nchunk != 2) return hipErrorInvalidValue;

@@ -36,6 +36,9 @@ struct ConvArgs {
     // lines instead of a 64-byte half of every pixel's lines.  Image stride is the same either way.
     int in_planar;         // input is planar (needs 64-byte chunks: steps == prec_maxsteps)
     int out_planar;        // output and residual are planar (cout_store a multiple of 64 bytes)
+    // transposed conv only: packed 64 x 27 tap-projection weights of the following <= 3-channel conv
+    // (conv_mfma.hip epilogue_proj); out is then the fp32 P tensor [B,2H,2W,32]; nullptr = plain epilogue
+    const void* proj_w;
     int dbg;               // ablation switches for tools/conv_bench.py (0 in production)
     unsigned long long* stamps;   // diagnostic build only (dbg & 64): per-phase cycle sums, else nullptr
 };
@@ -55,6 +58,8 @@ __host__ __device__ constexpr int tapsn_chunk(int prec) { return prec == P_BF16 
 // host-side launchers (conv_mfma.hip, conv_tapsn.hip)
 hipError_t launch_conv(int prec, int mode, int nt, int steps, const ConvArgs& a, int ncb, hipStream_t s);
 hipError_t launch_conv_tapsn(int prec, int nchunk, const ConvArgs& a, hipStream_t s);
+// out[y,x,co] = act(bias[co] + sum_tap P[y+ky-1, x+kx-1][tap*3+co]) (+ residual); a.in = P [B,H,W,32] fp32
+hipError_t launch_tap_gather(const ConvArgs& a, hipStream_t s);
 size_t conv_lds_bytes(int prec, int mode, int nt, int steps, int mt);
 
 // element-wise / gather kernels (fused_ops.hip).  act_bf16: activations are bf16.

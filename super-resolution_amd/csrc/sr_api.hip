@@ -36,6 +36,7 @@ struct ConvLayer {
     bool tapsn = false;   // <= 3 output channels: taps folded into N (conv_tapsn.hip)
     void* d_w = nullptr;
     float* d_bias = nullptr;
+    void* d_proj = nullptr;   // transposed conv fused with the following <= 3-channel conv: its tap-projection weights
     double wbytes = 0;
 };
 
@@ -238,8 +239,45 @@ int upload_layer(sr_ctx* c, ConvLayer& L, int prec, const float* w, const float*
 void free_layer(ConvLayer& L) {
     if (L.d_w) (void)hipFree(L.d_w);
     if (L.d_bias) (void)hipFree(L.d_bias);
+    if (L.d_proj) (void)hipFree(L.d_proj);
     L.d_w = nullptr;
     L.d_bias = nullptr;
+    L.d_proj = nullptr;
+}
+
+// Tap-projection weights for conv_mfma.hip epilogue_proj: the following conv's kernel w[3,3,64,cout<=3]
+// as a 64 x 32 matrix (column nn = tap*3 + co, 27 used), packed as MFMA A fragments whose K order is
+// the accumulator layout of the transposed conv: k-step (n, s), lane (nn, hh), element e holds channel
+//   n*32 + 16*s + 8*(e>>2) + 4*hh + (e&3).
+// [k-step][hi,lo][lane] x 16 B for bf16x3, [k-step][lane] for bf16, [k-step][e>>2][lane] for fp32.
+int upload_proj(sr_ctx* c, ConvLayer& L, int prec, const float* w, int cout) {
+    const int vps = prec == P_BF16 ? 1 : 2;
+    std::vector<uint8_t> out((size_t)4 * vps * 64 * 16, 0);
+    for (int n = 0; n < 2; ++n)
+        for (int s = 0; s < 2; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int nn = lane & 31, hh = lane >> 5, tap = nn / 3, co = nn % 3;
+                const size_t vbase = (size_t)(n * 2 + s) * vps * 64;
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = n * 32 + 16 * s + 8 * (e >> 2) + 4 * hh + (e & 3);
+                    const float v = (nn < 27 && co < cout) ? w[((size_t)tap * 64 + ch) * cout + co] : 0.f;
+                    if (prec == P_FP32) {
+                        memcpy(&out[(vbase + (e >> 2) * 64 + lane) * 16 + (e & 3) * 4], &v, 4);
+                    } else {
+                        const uint16_t hi = f2bf(v);
+                        memcpy(&out[(vbase + lane) * 16 + e * 2], &hi, 2);
+                        if (prec == P_BF16X3) {
+                            const uint16_t lo = f2bf(v - bf2f(hi));
+                            memcpy(&out[(vbase + 64 + lane) * 16 + e * 2], &lo, 2);
+                        }
+                    }
+                }
+            }
+    if (L.d_proj) (void)hipFree(L.d_proj);
+    L.d_proj = nullptr;
+    HIPCHK(c, hipMalloc(&L.d_proj, out.size()));
+    HIPCHK(c, hipMemcpy(L.d_proj, out.data(), out.size(), hipMemcpyHostToDevice));
+    return SR_OK;
 }
 
 // ---------------------------------------------------------------- profiling helpers
@@ -308,6 +346,7 @@ struct ConvIO {
     int res_cs;
     int act;
     int in_planar = 0, out_planar = 0;   // kernels.h: planes of 64 B per pixel
+    const void* proj_w = nullptr;        // transposed conv: fused tap projection, out = P [B,2H,2W,32] fp32
 };
 
 int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, const ConvIO& io, const char* name) {
@@ -328,6 +367,9 @@ int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, con
     a.act = io.act;
     a.in_planar = io.in_planar;
     a.out_planar = io.out_planar;
+    a.proj_w = io.proj_w;
+    if (io.proj_w && (L.mode != M_CONVT || L.cout != 64 || L.nt != 2 || !io.out_f32 || io.res))
+        return fail(c, SR_ERR_ARG, "%s: tap projection needs a 64-channel transposed conv", name);
     if (io.in_planar && (L.tapsn || L.steps != prec_maxsteps(prec, L.mode) || (L.mode == M_CONVT && L.nchunk != 1)))
         return fail(c, SR_ERR_ARG, "%s: planar input needs 64-byte chunks", name);
     if (io.out_planar && (L.tapsn || L.mode != M_CONV || (io.cout_store * (io.out_f32 ? 4 : 2)) % 64 || io.cout_store != io.out_cs ||
@@ -483,6 +525,29 @@ int run_srnet(sr_ctx* c, int B, float* d_out) {
     auto b = [&](const char* n) { return c->buf[n]; };
     int rc = run_conv(c, P, st, c->srnet[21], B, {b("sx"), H, W, b("up1"), 64, 64, af, nullptr, 0, A_RELU, c->planar_trunk, 0}, "srnet.up1");
     if (rc) return rc;
+    if (c->srnet[22].d_proj) {
+        // conv2d_transpose_2 + ReLU + the 64 x 27 tap projection of conv2d_36 in one kernel: "up2" holds
+        // P[B,4H,4W,32] (128 B per HR pixel instead of 256 B of activations), then the 9-tap gather
+        rc = run_conv(c, P, st, c->srnet[22], B, {b("up1"), 2 * H, 2 * W, b("up2"), 32, 32, 1, nullptr, 0, A_RELU, 0, 0, c->srnet[22].d_proj}, "srnet.up2");
+        if (rc) return rc;
+        ConvArgs g = {};
+        g.in = b("up2");
+        g.bias = c->srnet[23].d_bias;
+        g.out = d_out;
+        g.B = B;
+        g.H = 4 * H;
+        g.W = 4 * W;
+        g.out_cs = 3;
+        g.cout_store = 3;
+        g.out_f32 = 1;
+        g.act = A_CLIP01;
+        g.tiles_x = (g.W + TW - 1) / TW;
+        g.tiles_y = (g.H + 7) / 8;
+        const double px = (double)B * g.H * g.W;
+        ProfScope ps(c, "srnet.out", px * 27 * 2, px * (128 + 12));
+        LAUNCHCHK(c, "srnet.out", launch_tap_gather(g, st));
+        return SR_OK;
+    }
     rc = run_conv(c, P, st, c->srnet[22], B, {b("up1"), 2 * H, 2 * W, b("up2"), 64, 64, af, nullptr, 0, A_RELU}, "srnet.up2");
     if (rc) return rc;
     return run_conv(c, P, st, c->srnet[23], B, {b("up2"), 4 * H, 4 * W, d_out, 3, 3, 1, nullptr, 0, A_CLIP01}, "srnet.out");
@@ -675,6 +740,10 @@ int sr_commit_weights(sr_ctx* c) {
         srnet_spec(i, cin, cout, mode);
         plan_layer(c->srnet[i], c->prec, mode, cin, cout);
         int rc = upload_layer(c, c->srnet[i], c->prec, c->tensors[28 + 2 * i].data.data(), c->tensors[28 + 2 * i + 1].data.data());
+        if (rc) return rc;
+    }
+    if (!getenv("SR_NO_FUSE_OUT")) {   // SRNet tail: conv2d_transpose_2 carries conv2d_36's tap projection
+        int rc = upload_proj(c, c->srnet[22], c->prec, c->tensors[28 + 2 * 23].data.data(), 3);
         if (rc) return rc;
     }
     c->committed = true;
