@@ -838,21 +838,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
     struct TileXY {
         int b, y0, x0;
     };
-    auto decode = [&](int t) {
+    // tile order: 8x8-tile super tiles, row major inside; each XCD (workgroup id % 8) walks its own
+    // contiguous band of that order, so the tiles in flight on one XCD form a compact block and halo
+    // rows / columns are L2 hits instead of second HBM reads
+    const int per_img = a.tiles_x * a.tiles_y;
+    const int nsx = (a.tiles_x + 7) >> 3;
+    auto decode = [&](int tt) {
         TileXY q;
-        const int txi = t % a.tiles_x;
-        t /= a.tiles_x;
-        q.x0 = txi * TW;
-        q.y0 = (t % a.tiles_y) * G::TH;
-        q.b = t / a.tiles_y;
+        q.b = tt / per_img;
+        int rem = tt - q.b * per_img;
+        if (a.dbg & 32) {   // ablation: plain row-major tiles
+            q.y0 = (rem / a.tiles_x) * G::TH;
+            q.x0 = (rem % a.tiles_x) * TW;
+            return q;
+        }
+        const int sy = rem / (8 * a.tiles_x);
+        rem -= sy * 8 * a.tiles_x;
+        const int rows = min(8, a.tiles_y - 8 * sy);
+        const int sx = min(rem / (rows * 8), nsx - 1);
+        rem -= sx * rows * 8;
+        const int cols = min(8, a.tiles_x - 8 * sx);
+        const int iy = rem / cols, ix = rem - iy * cols;
+        q.y0 = (8 * sy + iy) * G::TH;
+        q.x0 = (8 * sx + ix) * TW;
         return q;
     };
 
     // persistent over tiles blockIdx.x, blockIdx.x + gridDim.x, ...: the (tile, chunk) sequence is one
     // software pipeline, so a tile's first chunk is fetched under the previous tile's last chunk and
     // its stores drain under the next tile's MFMAs
-    int t = blockIdx.x;
-    if (t >= ntiles) return;
+    const int per_xcd = (ntiles + 7) / 8;
+    const bool band = !(a.dbg & 32);
+    const int nslot = band ? gridDim.x >> 3 : gridDim.x;
+    const int t_end = band ? min(ntiles, ((int)(blockIdx.x & 7) + 1) * per_xcd) : ntiles;
+    int t = band ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    if (t >= t_end) return;
     TileXY cur = decode(t);
     // halo origin of a tile (row y0-1, column x0-1; never dereferenced where it lies outside the image)
     auto tile_base = [&](const TileXY& q) {
@@ -889,8 +909,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[m][n][4 * g + j] = bv[j];
             }
-        const int tn = t + gridDim.x;
-        const bool have_next = tn < ntiles;
+        const int tn = t + nslot;
+        const bool have_next = tn < t_end;
         const TileXY nxt = decode(have_next ? tn : t);
         const unsigned nxt_mask = tile_mask<G>(tid, nxt.y0, nxt.x0, H, W);
         for (int c = 0; c < a.nchunk; ++c) {
@@ -1048,10 +1068,11 @@ static hipError_t launch_k(K kernel, size_t lds, ConvArgs a, int th, int ncb, hi
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + th - 1) / th;
     int gx = a.tiles_x * a.tiles_y * a.B;
-    if (wg_per_cu > 0) {   // persistent: every workgroup the same number of tiles (+-1)
-        const int maxwg = std::max(1, wg_per_cu * num_cus() / ncb);
-        const int iters = (gx + maxwg - 1) / maxwg;
-        gx = (gx + iters - 1) / iters;
+    if (wg_per_cu > 0) {   // persistent: one band of tiles per XCD, every workgroup the same number of tiles (+-1)
+        const int per_xcd = (gx + 7) / 8;
+        const int max_slots = std::max(1, wg_per_cu * num_cus() / ncb / 8);
+        const int rounds = (per_xcd + max_slots - 1) / max_slots;
+        gx = 8 * ((per_xcd + rounds - 1) / rounds);
     }
     hipLaunchKernelGGL(kernel, dim3(gx, ncb), dim3(256), lds, s, a);
     return hipGetLastError();

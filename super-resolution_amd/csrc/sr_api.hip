@@ -1059,7 +1059,10 @@ int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, in
     HIPCHK(nullptr, hipMemcpy(d_x, x.data(), npix * Cin * 4, hipMemcpyHostToDevice));
     LAUNCHCHK(nullptr, "pad_channels", launch_pad_channels(d_x, d_xp, dtype == SR_BF16, (long)npix, Cin, L.cin_p, nullptr));
     HIPCHK(nullptr, hipMemset(d_out, 0, opix * cout_p * 4));
-    const ConvIO io{d_xp, H, W, d_out, cout_p, Cout, out_f32 ? 1 : 0, residual ? d_out : nullptr, cout_p, A_RELU};
+    ConvIO io{d_xp, H, W, d_out, cout_p, Cout, out_f32 ? 1 : 0, residual ? d_out : nullptr, cout_p, A_RELU};
+    if (getenv("SR_BENCH_PLANAR") && mode == M_CONV && !L.tapsn && L.steps == prec_maxsteps(dtype, mode) &&
+        cout_p == Cout && (Cout * es) % 64 == 0)
+        io.in_planar = io.out_planar = 1;   // the SRNet trunk's production layout
     for (int i = 0; i < 3; ++i)
         if ((rc = run_conv(nullptr, dtype, nullptr, L, B, io, "bench_conv"))) return rc;
     if (g_conv_dbg & 64) {
