@@ -87,6 +87,22 @@ def kernel_profile(torch, ctx, lr_dev, steps):
     return prof
 
 
+def pmc_traffic(dtype):
+    """HBM bytes per launch of the res-block conv from the committed PMC passes (counters need
+    their own rocprofv3 runs, so they cannot be read live here); None when no pass is on file."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")))
+        tag = {"bf16x3": "conv3x3_lds_kernel<2, 2, 1, true>", "bf16": "conv3x3_lds_kernel<1, 2, 2, true>",
+               "fp32": "conv3x3_lds_kernel<0, 2, 2, true>"}[dtype]
+        best = None
+        for k, v in d["kernels"].items():   # the trunk's grid is the one with the most launches
+            if k.startswith(tag) and (best is None or v["launches"] > best["launches"]):
+                best = v
+        return best["hbm_bytes"] if best else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(weights, lr):
     """The torch-CPU restatement (oracle/ref_torch.py; kind 'port': the reference's
     TF1/Keras path cannot run here) on a bounded sample: 1 clip, 1 warm-up + 3 timed
@@ -168,8 +184,11 @@ def main():
         alg_flops = RES_CONV_FLOP_PER_LR_PX * CLIPS * H_LR * W_LR      # credited on the unpadded 180 rows
         achieved = alg_flops / (avg_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
-        out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_kernel (srnet.res, 64->64)", "achieved": round(achieved, 2),
-                           "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+        out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_lds_kernel (srnet.res, 64->64 3x3, 20 launches/step)",
+                           "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                           "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.dtype),
+                           "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate "
+                                           "passes, profiles/r1_hbm_traffic.json); algorithmic 723 MB",
                            "avg_launch_ms": round(avg_ms, 4), "launches_timed": res["launches"]}
         tot = sum(p["ms_total"] for p in prof)
         out["kernel_ms_per_step"] = {p["name"]: round(p["ms_total"] / max(1, res["launches"] // 20), 4) for p in prof}
@@ -179,6 +198,12 @@ def main():
         out["hbm_kernel"] = {"kernel": "pre_srnet_kernel", "bound": "hbm",
                              "achieved": round(pre["bytes_per_launch"] / (pre_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
                              "unit": "GB/s", "avg_launch_ms": round(pre_ms, 4)}
+        tail = next((p for p in prof if p["name"] == "srnet.out"), None)
+        if tail:   # the 9-tap gather after the fused transposed conv: 128 B in + 12 B out per HR pixel
+            t_ms = tail["ms_total"] / tail["launches"]
+            out["hbm_kernel2"] = {"kernel": "tap_gather_kernel (srnet.out)", "bound": "hbm",
+                                  "achieved": round(tail["bytes_per_launch"] / (t_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                                  "unit": "GB/s", "avg_launch_ms": round(t_ms, 4)}
         ctx.close()
         others = {}
         for d in ("fp32", "bf16", "bf16x3"):

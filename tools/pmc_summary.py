@@ -19,13 +19,9 @@ import sys
 
 
 def short(name):
-    name = name.split("(")[0]
-    for tag in ("conv3x3_lds_kernel", "conv3x3_tapsn_kernel", "conv3x3_kernel"):
-        if tag in name:
-            # keep the template arguments: precision, NT / mode, steps
-            i = name.index(tag)
-            return name[i:].replace("sr::", "")
-    return name.split("::")[-1]
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    name = name.split("(")[0]            # drop the argument list, keep the template arguments
+    return name.replace("sr::", "")
 
 
 def per_kernel(path, counter):
