@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace sr {
 
@@ -1034,11 +1035,119 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// M_CONVT with the weights shared through LDS.  conv3x3_kernel lets each of the 4 waves stream all
+// weights of the layer (147 KiB for 64->64 bf16x3) from L2 through its own register ring: 4x the
+// vector-L1 traffic and a ring too shallow for the L2 latency.  Here the workgroup copies one TAP's
+// weights (all input channels, both N blocks: 16 KiB) into one of two LDS buffers while the previous
+// tap computes: every thread moves 4 vectors per tap, and the MFMA loop reads only LDS.
+// Needs the whole input-channel range in one chunk (nchunk == 1) and NT == 2.
+template <int PREC, int STEPS>
+__global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) {
+    using G = Geo<PREC, M_CONVT, 2, STEPS>;
+    constexpr int NB = 2 * G::BV;                 // weight vectors per lane per k-step
+    constexpr int TAPV = STEPS * G::STEPV;        // 16-B vectors of one tap
+    static_assert(TAPV % 256 == 0, "a tap's weights split evenly over the workgroup");
+    constexpr int WIT = TAPV / 256;
+    constexpr int A_BYTES = G::TILE_BYTES * G::AV;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* smem_b = smem + A_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    int tile = blockIdx.x;
+    const int txi = tile % a.tiles_x;
+    tile /= a.tiles_x;
+    const int tyi = tile % a.tiles_y;
+    const int b = tile / a.tiles_y;
+    const int x0 = txi * TW, y0 = tyi * G::TH;
+    const int H = a.H, W = a.W;
+
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpack) + (size_t)blockIdx.y * a.wstride_cb + tid;
+    const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * H * W * a.cin_p * G::ESZ;
+
+    u32x4 regs_w[WIT];
+    auto load_tap = [&](int q) {   // taps are packed in consumption order: pass major, tap, step, n, hi/lo, lane
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) regs_w[it] = wsrc[(size_t)q * TAPV + it * 256];
+    };
+    auto store_tap = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            *reinterpret_cast<u32x4*>(smem_b + (size_t)buf * TAPV * 16 + (it * 256 + tid) * 16) = regs_w[it];
+    };
+
+    {
+        u32x4 regs[G::ITER];
+        stage_load<G, PREC>(regs, inb, 0, a.cin_p, y0, x0, H, W, tid, a.in_planar);
+        load_tap(0);
+        stage_store<G, PREC>(regs, smem, tid);
+    }
+    store_tap(0);
+    load_tap(1);
+    __syncthreads();
+
+    f32x16 acc[G::MT][2];
+    const unsigned char* bl = smem_b + lane * 16;
+    // tap sequence: pass 0 = taps {0,2,6,8}, pass 1 = {1,7}, pass 2 = {3,5}, pass 3 = {4}
+    auto tap_iter = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int pass = q < 4 ? 0 : (q < 6 ? 1 : (q < 8 ? 2 : 3));
+        constexpr int tidx = q < 4 ? q : (q < 6 ? q - 4 : (q < 8 ? q - 6 : 0));
+        constexpr int tap = pass_tap(M_CONVT, pass, tidx);
+        constexpr bool first = tidx == 0, last = tidx + 1 == pass_ntaps(M_CONVT, pass);
+        if (q + 1 < 9) store_tap((q + 1) & 1);   // its previous contents (tap q-1) were released by the last barrier
+        if (q + 2 < 9) load_tap(q + 2);          // lands during this tap's MFMAs
+        if (first) zero_acc<G, 2>(acc);
+        const unsigned char* bq = bl + (size_t)(q & 1) * TAPV * 16;
+        u32x4 fa[2][G::MT][G::AV], fb[2][NB];
+        load_a<G, M_CONVT>(fa[0], smem, tap, 0, wave, r, h);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) fb[0][j] = *reinterpret_cast<const u32x4*>(bq + j * 1024);
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            if (i + 1 < STEPS) {
+                load_a<G, M_CONVT>(fa[(i + 1) & 1], smem, tap, i + 1, wave, r, h);
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    fb[(i + 1) & 1][j] = *reinterpret_cast<const u32x4*>(bq + ((i + 1) * NB + j) * 1024);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                if constexpr (PREC == P_BF16X3) {
+                    mma_wx<PREC, true>(acc[0][n], fb[i & 1][n * 2 + 0], fa[i & 1][0][1]);   // w_hi * x_lo
+                    mma_wx<PREC, true>(acc[0][n], fb[i & 1][n * 2 + 1], fa[i & 1][0][0]);   // w_lo * x_hi
+                    mma_wx<PREC, true>(acc[0][n], fb[i & 1][n * 2 + 0], fa[i & 1][0][0]);   // w_hi * x_hi
+                } else {
+                    mma_wx<PREC, true>(acc[0][n], fb[i & 1][n], fa[i & 1][0][0]);
+                }
+            }
+        }
+        if (last) {
+            if (a.proj_w) epilogue_proj<G, PREC>(acc, a, pass, b, y0, x0, wave, lane);
+            else epilogue<G, M_CONVT, 2, true>(acc, a, pass, b, y0, x0, wave, r, h);
+        }
+        if (q + 1 < 9) __syncthreads();   // tap q+1 is in LDS for every wave; tap q's buffer is free
+    };
+    tap_iter(std::integral_constant<int, 0>{});
+    tap_iter(std::integral_constant<int, 1>{});
+    tap_iter(std::integral_constant<int, 2>{});
+    tap_iter(std::integral_constant<int, 3>{});
+    tap_iter(std::integral_constant<int, 4>{});
+    tap_iter(std::integral_constant<int, 5>{});
+    tap_iter(std::integral_constant<int, 6>{});
+    tap_iter(std::integral_constant<int, 7>{});
+    tap_iter(std::integral_constant<int, 8>{});
+}
+
 size_t conv_lds_bytes(int prec, int mode, int nt, int steps, int mt) {
     const int th = mode == M_CONV ? 4 * mt : 4, hb = mode == M_CONV ? 1 : 0;
     const size_t tile = (size_t)(th + 1 + hb) * (TW + 1 + hb) * (32 * steps + 16);
     const size_t a = prec == P_BF16X3 ? 2 * tile : tile;
-    if (mode == M_CONVT) return a;
+    if (mode == M_CONVT) return a + (nt == 2 ? (size_t)2 * steps * nt * (prec == P_BF16X3 ? 2 : 1) * 1024 : 0);   // + two tap buffers
     const size_t bv = prec == P_BF16X3 ? 2 : 1;
     const size_t ab = a + (size_t)9 * steps * nt * bv * 1024;   // + the chunk's weights
     const size_t scratch = (size_t)4 * 64 * (nt * 32 * 4 + 16);  // epilogue_lds, fp32 rows (the larger case)
@@ -1085,6 +1194,13 @@ static hipError_t launch_one(const ConvArgs& a, int ncb, hipStream_t s) {
         return launch_k(&conv3x3_lds_kernel<PREC, NT, STEPS, true>, conv_lds_bytes(PREC, MODE, NT, STEPS, 2), a, 8,
                         ncb, s, attr_done, 2);
     } else {
+        if constexpr (NT == 2 && (STEPS * Geo<PREC, MODE, NT, STEPS>::STEPV) % 256 == 0) {
+            if (a.nchunk == 1 && !(a.dbg & 128)) {
+                static bool attr2 = false;
+                return launch_k(&convT3x3_lds_kernel<PREC, STEPS>, conv_lds_bytes(PREC, MODE, NT, STEPS, 1), a, 4, ncb, s,
+                                attr2, 0);
+            }
+        }
         return launch_k(&conv3x3_kernel<PREC, MODE, NT, STEPS>, conv_lds_bytes(PREC, MODE, NT, STEPS, 1), a, 4, ncb,
                         s, attr_done, 0);
     }
