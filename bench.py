@@ -70,7 +70,7 @@ def time_steps(torch, dist, ctx, lr_dev, steps, warmup, world):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -143,9 +143,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libsr_hip has no CPU fallback")
+    # one process per GPU; SR_BENCH_BACKEND=gloo lets several ranks rehearse on a one-GPU box
+    backend = os.environ.get("SR_BENCH_BACKEND", "nccl")
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import sr_hip
     from oracle import ref_numpy as rn
