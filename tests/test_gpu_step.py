@@ -71,6 +71,27 @@ def test_step_vs_oracle_fp32(sh, weights7, h, w, B):
     ctx.close()
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("env", ["SR_NO_PLANAR", "SR_NO_FUSE_OUT", "SR_NO_TAPSN"])
+def test_layout_switches_keep_parity(sh, weights7, env, dtype):
+    """The A/B switches (NHWC trunk instead of 64-byte planes; unfused transposed conv + 64->3 conv;
+    generic kernel for the <=3-channel convs) select older kernels of the same path: same bar."""
+    lr_t, lr_tm1, est = step_inputs(300, 2, 24, 40)
+    want, want_lw = rt.generator_step(weights7, lr_t, lr_tm1, est)
+    os.environ[env] = "1"
+    if env == "SR_NO_TAPSN":
+        os.environ["SR_NO_FUSE_OUT"] = "1"
+    try:
+        ctx = make_ctx(sh, weights7, 24, 40, 2, dtype=dtype)
+        got, lw = ctx.step(lr_t, lr_tm1, est)
+        ctx.close()
+    finally:
+        os.environ.pop(env, None)
+        os.environ.pop("SR_NO_FUSE_OUT", None)
+    assert np.abs(got - want).max() <= FP32_TOL
+    assert np.abs(lw - want_lw).max() <= FP32_TOL
+
+
 def test_golden_clip24x40(sh, weights7):
     g = np.load(os.path.join(GOLD, "clip24x40.npz"))
     clip = rn.synth_clip(int(g["clip_id"]), 3, 24, 40)[:, None]
