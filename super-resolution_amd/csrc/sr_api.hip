@@ -83,6 +83,15 @@ struct sr_ctx {
     int clip_B = 0, cur = 0;
     int trunk_sub = 0;   // clips per trunk sub-batch (0 = whole batch)
     int planar_trunk = 1;   // SRNet trunk activations (sx, sy) in 64-byte planes; SR_NO_PLANAR=1 disables
+    // two lanes: a step's batch is split into halves that run on `stream` and on `stream2` between a
+    // fork and a join event, so one half's kernels fill the partial last round of workgroups (and the
+    // under-filled low-resolution FNet launches) of the other.  SR_NO_DUAL=1 disables.
+    int dual = 1;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t lane_stream = nullptr;   // stream of the lane being enqueued (nullptr: `stream`)
+    int lane_b0 = 0;                     // first image of that lane
+    std::map<std::string, size_t> buf_img_bytes;   // bytes per image of every named activation buffer
     // profiling
     bool prof_on = false;
     std::vector<ProfEntry> prof;
@@ -313,11 +322,11 @@ struct ProfScope {
         p->launches++;
         e0 = get_event(c);
         e1 = get_event(c);
-        (void)hipEventRecord(e0, c->stream);
+        (void)hipEventRecord(e0, c->lane_stream ? c->lane_stream : c->stream);
     }
     ~ProfScope() {
         if (!e0) return;
-        (void)hipEventRecord(e1, c->stream);
+        (void)hipEventRecord(e1, c->lane_stream ? c->lane_stream : c->stream);
         c->prof[idx].pending.emplace_back(e0, e1);
     }
 };
@@ -413,7 +422,14 @@ int alloc_buf(sr_ctx* c, const char* name, size_t bytes) {
     void* p = nullptr;
     HIPCHK(c, hipMalloc(&p, bytes));
     c->buf[name] = p;
+    c->buf_img_bytes[name] = bytes / (size_t)c->max_batch;
     return SR_OK;
+}
+
+// stream and activation buffers of the lane being enqueued (whole batch on `stream` outside a fork)
+hipStream_t lane_st(const sr_ctx* c) { return c->lane_stream ? c->lane_stream : c->stream; }
+void* lane_buf(sr_ctx* c, const char* name) {
+    return (unsigned char*)c->buf[name] + (size_t)c->lane_b0 * c->buf_img_bytes[name];
 }
 
 // expected (cin, cout, mode) of every weighted layer, reference layers.py:30-44,67-75
@@ -438,9 +454,9 @@ int check_ready(sr_ctx* c, int B) {
 int run_fnet(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, float* d_flow) {
     const int bf = c->prec == P_BF16, P = c->prec;
     const int af = bf ? 0 : 1;   // activations are float?
-    hipStream_t st = c->stream;
+    hipStream_t st = lane_st(c);
     const int H = c->h, W = c->w;
-    auto b = [&](const char* n) { return c->buf[n]; };
+    auto b = [&](const char* n) { return lane_buf(c, n); };
     {
         ProfScope ps(c, "fnet.input", 0, (double)B * H * W * (24 + 16 * (bf ? 2 : 4)));
         LAUNCHCHK(c, "fnet.input", launch_fnet_input(d_lr_t, d_lr_tm1, b("x0"), bf, B, H, W, st));
@@ -501,16 +517,16 @@ int run_fnet(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, float
 // layers instead of streaming through HBM 41 times per frame.
 int run_srnet(sr_ctx* c, int B, float* d_out) {
     const int P = c->prec, af = c->prec == P_BF16 ? 0 : 1;
-    hipStream_t st = c->stream;
+    hipStream_t st = lane_st(c);
     const int H = c->h, W = c->w;
     const size_t es = af ? 4 : 2;
     const int sub = c->trunk_sub > 0 ? c->trunk_sub : B;
     for (int b0 = 0; b0 < B; b0 += sub) {
         const int nb = b0 + sub <= B ? sub : B - b0;
         const size_t off = (size_t)b0 * H * W * 64 * es;
-        unsigned char* s_in = (unsigned char*)c->buf["s_in"] + off;
-        unsigned char* sx = (unsigned char*)c->buf["sx"] + off;
-        unsigned char* sy = (unsigned char*)c->buf["sy"] + off;
+        unsigned char* s_in = (unsigned char*)lane_buf(c, "s_in") + off;
+        unsigned char* sx = (unsigned char*)lane_buf(c, "sx") + off;
+        unsigned char* sy = (unsigned char*)lane_buf(c, "sy") + off;
         const int pl = c->planar_trunk;   // trunk activations in 64-byte planes (kernels.h)
         int rc = run_conv(c, P, st, c->srnet[0], nb, {s_in, H, W, sx, 64, 64, af, nullptr, 0, A_RELU, 0, pl}, "srnet.head");
         if (rc) return rc;
@@ -522,7 +538,7 @@ int run_srnet(sr_ctx* c, int B, float* d_out) {
             if (rc) return rc;
         }
     }
-    auto b = [&](const char* n) { return c->buf[n]; };
+    auto b = [&](const char* n) { return lane_buf(c, n); };
     int rc = run_conv(c, P, st, c->srnet[21], B, {b("sx"), H, W, b("up1"), 64, 64, af, nullptr, 0, A_RELU, c->planar_trunk, 0}, "srnet.up1");
     if (rc) return rc;
     if (c->srnet[22].d_proj) {
@@ -554,22 +570,23 @@ int run_srnet(sr_ctx* c, int B, float* d_out) {
 }
 
 // one generator step on device buffers (reference FRVSR.py:58-63, TecoGAN.py:68-76)
-int run_step(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, const float* d_est_prev,
-             float* d_est_out, float* d_lr_warp, float* d_hr_warp, bool warp_only) {
+int run_step_lane(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, const float* d_est_prev,
+                  float* d_est_out, float* d_lr_warp, float* d_hr_warp, bool warp_only) {
     const int bf = c->prec == P_BF16;
     const int H = c->h, W = c->w;
-    hipStream_t st = c->stream;
-    int rc = run_fnet(c, B, d_lr_t, d_lr_tm1, c->d_flow);
+    hipStream_t st = lane_st(c);
+    float* d_flow = c->d_flow + (size_t)c->lane_b0 * H * W * 2;
+    int rc = run_fnet(c, B, d_lr_t, d_lr_tm1, d_flow);
     if (rc) return rc;
     if (d_lr_warp) {
         ProfScope ps(c, "lr_warp", 0, (double)B * H * W * 4 * (3 + 2 + 3));
-        LAUNCHCHK(c, "lr_warp", launch_warp3(d_lr_tm1, c->d_flow, d_lr_warp, B, H, W, st));
+        LAUNCHCHK(c, "lr_warp", launch_warp3(d_lr_tm1, d_flow, d_lr_warp, B, H, W, st));
     }
     {
         // algorithmic bytes per LR pixel: read 2 flow + 48 prev-est + 3 LR (fp32), write 64 activations
         const double bytes = (double)B * H * W * (4.0 * (2 + 48 + 3) + 64.0 * (bf ? 2 : 4) + (d_hr_warp ? 192.0 : 0.0));
         ProfScope ps(c, "pre_srnet", 0, bytes);
-        LAUNCHCHK(c, "pre_srnet", launch_pre_srnet(c->d_flow, d_est_prev, d_lr_t, c->buf["s_in"], d_hr_warp, bf, B, H, W, st));
+        LAUNCHCHK(c, "pre_srnet", launch_pre_srnet(d_flow, d_est_prev, d_lr_t, lane_buf(c, "s_in"), d_hr_warp, bf, B, H, W, st));
     }
     if (warp_only) return SR_OK;
     rc = run_srnet(c, B, d_est_out);
@@ -578,6 +595,34 @@ int run_step(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, const
         ProfScope ps(c, "teco_epilogue", 0, (double)B * H * W * (12.0 + 2 * 192.0));
         LAUNCHCHK(c, "teco_epilogue", launch_teco_epilogue(d_est_out, d_lr_t, B, H, W, st));
     }
+    return SR_OK;
+}
+
+int run_step(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, const float* d_est_prev,
+             float* d_est_out, float* d_lr_warp, float* d_hr_warp, bool warp_only) {
+    // profiling wants each kernel alone on the device; one image cannot be split
+    if (!c->dual || !c->stream2 || B < 2 || c->prof_on)
+        return run_step_lane(c, B, d_lr_t, d_lr_tm1, d_est_prev, d_est_out, d_lr_warp, d_hr_warp, warp_only);
+    const size_t lr = (size_t)c->h * c->w * 3, hr = lr * 16;
+    const int nb[2] = {(B + 1) / 2, B / 2};
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    int rc = SR_OK;
+    for (int lane = 0; lane < 2 && rc == SR_OK; ++lane) {
+        const int b0 = lane == 0 ? 0 : nb[0];
+        c->lane_b0 = b0;
+        c->lane_stream = lane == 0 ? c->stream : c->stream2;
+        rc = run_step_lane(c, nb[lane], d_lr_t + b0 * lr, d_lr_tm1 + b0 * lr, d_est_prev + b0 * hr,
+                           d_est_out ? d_est_out + b0 * hr : nullptr, d_lr_warp ? d_lr_warp + b0 * lr : nullptr,
+                           d_hr_warp ? d_hr_warp + b0 * hr : nullptr, warp_only);
+    }
+    c->lane_b0 = 0;
+    c->lane_stream = nullptr;
+    // always join, also after a failed launch, so that `stream` stays ordered behind `stream2`
+    hipError_t e1 = hipEventRecord(c->ev_join, c->stream2);
+    hipError_t e2 = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    if (rc) return rc;
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(c, SR_ERR_HIP, "stream join failed");
     return SR_OK;
 }
 
@@ -629,6 +674,11 @@ int sr_create(sr_ctx** out, int device, int h, int w, int ch, int scale, int max
     if (hipSetDevice(device) != hipSuccess) return bail(fail(c, SR_ERR_HIP, "hipSetDevice(%d) failed", device));
     if (hipStreamCreate(&c->stream) != hipSuccess) return bail(fail(c, SR_ERR_HIP, "hipStreamCreate failed"));
     c->own_stream = true;
+    if (getenv("SR_NO_DUAL")) c->dual = 0;
+    if (c->dual && (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess))
+        return bail(fail(c, SR_ERR_HIP, "second stream / events could not be created"));
     const size_t es = dtype == SR_BF16 ? 2 : 4;
     const size_t B = max_batch, L0 = (size_t)h * w, L1 = L0 / 4, L2 = L0 / 16, L3 = L0 / 64;
     struct { const char* n; size_t elems; } plan[] = {
@@ -653,6 +703,12 @@ int sr_destroy(sr_ctx* c) {
     if (!c) return SR_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) {
+        (void)hipStreamSynchronize(c->stream2);
+        (void)hipStreamDestroy(c->stream2);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     prof_resolve(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto& kv : c->buf) (void)hipFree(kv.second);
