@@ -86,9 +86,9 @@ struct sr_ctx {
     // two lanes: a step's batch is split into halves that run on `stream` and on `stream2` between a
     // fork and a join event, so one half's kernels fill the partial last round of workgroups (and the
     // under-filled low-resolution FNet launches) of the other.  SR_NO_DUAL=1 disables.
-    int dual = 1;
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int dual = 1;                        // number of extra lanes (0 = single stream); SR_LANES=n sets n-1
+    hipStream_t stream2[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     hipStream_t lane_stream = nullptr;   // stream of the lane being enqueued (nullptr: `stream`)
     int lane_b0 = 0;                     // first image of that lane
     std::map<std::string, size_t> buf_img_bytes;   // bytes per image of every named activation buffer
@@ -601,28 +601,32 @@ int run_step_lane(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, 
 int run_step(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, const float* d_est_prev,
              float* d_est_out, float* d_lr_warp, float* d_hr_warp, bool warp_only) {
     // profiling wants each kernel alone on the device; one image cannot be split
-    if (!c->dual || !c->stream2 || B < 2 || c->prof_on)
+    const int lanes = std::min(c->dual + 1, B);
+    if (lanes < 2 || c->prof_on)
         return run_step_lane(c, B, d_lr_t, d_lr_tm1, d_est_prev, d_est_out, d_lr_warp, d_hr_warp, warp_only);
     const size_t lr = (size_t)c->h * c->w * 3, hr = lr * 16;
-    const int nb[2] = {(B + 1) / 2, B / 2};
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    int rc = SR_OK;
-    for (int lane = 0; lane < 2 && rc == SR_OK; ++lane) {
-        const int b0 = lane == 0 ? 0 : nb[0];
+    for (int l = 1; l < lanes; ++l) HIPCHK(c, hipStreamWaitEvent(c->stream2[l - 1], c->ev_fork, 0));
+    int rc = SR_OK, b0 = 0;
+    for (int lane = 0; lane < lanes && rc == SR_OK; ++lane) {
+        const int nb = B / lanes + (lane < B % lanes ? 1 : 0);
         c->lane_b0 = b0;
-        c->lane_stream = lane == 0 ? c->stream : c->stream2;
-        rc = run_step_lane(c, nb[lane], d_lr_t + b0 * lr, d_lr_tm1 + b0 * lr, d_est_prev + b0 * hr,
+        c->lane_stream = lane == 0 ? c->stream : c->stream2[lane - 1];
+        rc = run_step_lane(c, nb, d_lr_t + b0 * lr, d_lr_tm1 + b0 * lr, d_est_prev + b0 * hr,
                            d_est_out ? d_est_out + b0 * hr : nullptr, d_lr_warp ? d_lr_warp + b0 * lr : nullptr,
                            d_hr_warp ? d_hr_warp + b0 * hr : nullptr, warp_only);
+        b0 += nb;
     }
     c->lane_b0 = 0;
     c->lane_stream = nullptr;
-    // always join, also after a failed launch, so that `stream` stays ordered behind `stream2`
-    hipError_t e1 = hipEventRecord(c->ev_join, c->stream2);
-    hipError_t e2 = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    // always join, also after a failed launch, so that `stream` stays ordered behind the other lanes
+    bool ok = true;
+    for (int l = 1; l < lanes; ++l) {
+        ok &= hipEventRecord(c->ev_join[l - 1], c->stream2[l - 1]) == hipSuccess;
+        ok &= hipStreamWaitEvent(c->stream, c->ev_join[l - 1], 0) == hipSuccess;
+    }
     if (rc) return rc;
-    if (e1 != hipSuccess || e2 != hipSuccess) return fail(c, SR_ERR_HIP, "stream join failed");
+    if (!ok) return fail(c, SR_ERR_HIP, "stream join failed");
     return SR_OK;
 }
 
@@ -675,9 +679,12 @@ int sr_create(sr_ctx** out, int device, int h, int w, int ch, int scale, int max
     if (hipStreamCreate(&c->stream) != hipSuccess) return bail(fail(c, SR_ERR_HIP, "hipStreamCreate failed"));
     c->own_stream = true;
     if (getenv("SR_NO_DUAL")) c->dual = 0;
-    if (c->dual && (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-                    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess))
+    if (const char* e = getenv("SR_LANES")) c->dual = std::max(0, std::min(3, atoi(e) - 1));
+    bool lanes_ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int l = 0; l < c->dual; ++l)
+        lanes_ok = lanes_ok && hipStreamCreateWithFlags(&c->stream2[l], hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&c->ev_join[l], hipEventDisableTiming) == hipSuccess;
+    if (!lanes_ok)
         return bail(fail(c, SR_ERR_HIP, "second stream / events could not be created"));
     const size_t es = dtype == SR_BF16 ? 2 : 4;
     const size_t B = max_batch, L0 = (size_t)h * w, L1 = L0 / 4, L2 = L0 / 16, L3 = L0 / 64;
@@ -703,12 +710,14 @@ int sr_destroy(sr_ctx* c) {
     if (!c) return SR_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->stream2) {
-        (void)hipStreamSynchronize(c->stream2);
-        (void)hipStreamDestroy(c->stream2);
+    for (int l = 0; l < 3; ++l) {
+        if (c->stream2[l]) {
+            (void)hipStreamSynchronize(c->stream2[l]);
+            (void)hipStreamDestroy(c->stream2[l]);
+        }
+        if (c->ev_join[l]) (void)hipEventDestroy(c->ev_join[l]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     prof_resolve(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto& kv : c->buf) (void)hipFree(kv.second);
