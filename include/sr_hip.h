@@ -62,7 +62,10 @@ int sr_create(sr_ctx** out, int device, int h, int w, int ch, int scale,
               int max_batch, int dtype, int model);
 int sr_destroy(sr_ctx* ctx);
 
-/* Run the ctx's kernels on this hipStream_t (default: a stream the ctx owns). */
+/* Run the ctx's kernels on this hipStream_t (default: a stream the ctx owns).  A step forks half of
+ * its batch onto a second, internal stream and joins it back with events before the call's last
+ * operation on this stream, so the caller sees plain stream order (environment SR_NO_DUAL=1: one
+ * stream only; SR_LANES=n: n lanes). */
 int sr_set_stream(sr_ctx* ctx, void* hip_stream);
 int sr_sync(sr_ctx* ctx);
 
