@@ -709,11 +709,14 @@ __device__ __forceinline__ void stage_store_p(const u32x4 (&regs)[G::ITER], unsi
 // uniform base plus one per-lane offset computed once.
 template <class G, int NT, typename OT>
 __device__ __forceinline__ void epilogue_lds_fast(const f32x16 (&acc)[G::MT][NT], const ConvArgs& a, int b, int y0, int x0,
-                                                  int wave, int lane, unsigned char* smem) {
+                                                  int wave, int lane, unsigned char* smem, unsigned long long (&es)[4], bool stamp) {
     using E = EpiLds<G, NT, OT>;
+    unsigned long long e0 = stamp ? __builtin_readcyclecounter() : 0ull;
     constexpr int SZ = (int)sizeof(OT);
     const int r = lane & 31, h = lane >> 5;
-    const int act = a.act;
+    // one uniform multiplier instead of a per-element choice of activation (which compiles to a scalar
+    // compare-and-branch per accumulator register: 1600 instructions for these 16 LDS stores)
+    const float slope = a.act == A_RELU ? 0.f : (a.act == A_LRELU ? 0.2f : 1.f);
     unsigned char* sc = smem + wave * E::WAVE_BYTES;
     const int prow = lane / E::LPR, chunk = lane % E::LPR;
     const int co = blockIdx.y * NT * 32 + chunk * (16 / SZ);
@@ -741,6 +744,7 @@ __device__ __forceinline__ void epilogue_lds_fast(const f32x16 (&acc)[G::MT][NT]
                 rr[k] = *reinterpret_cast<const u32x4*>(rb + (size_t)prel * pxs_r + vo_res);
             }
         }
+        if (stamp) { unsigned long long e1 = __builtin_readcyclecounter(); es[0] += e1 - e0; e0 = e1; }
 #pragma unroll
         for (int m = 2 * mg; m < 2 * mg + 2; ++m) {
 #pragma unroll
@@ -751,7 +755,7 @@ __device__ __forceinline__ void epilogue_lds_fast(const f32x16 (&acc)[G::MT][NT]
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float t = acc[m][n][4 * g + j];
-                        v[j] = act == A_RELU ? fmaxf(t, 0.f) : (act == A_LRELU ? fmaxf(t, 0.2f * t) : t);
+                        v[j] = fmaxf(t, slope * t);   // ReLU: slope 0, LeakyReLU: 0.2, none: 1 (max(t, t) = t)
                     }
                     unsigned char* dst = wr + (m & 1) * 32 * E::ROW + (n * 32 + 8 * g) * SZ;
                     if constexpr (SZ == 4) {
@@ -766,10 +770,12 @@ __device__ __forceinline__ void epilogue_lds_fast(const f32x16 (&acc)[G::MT][NT]
                 }
             }
         }
+        if (stamp) { unsigned long long e1 = __builtin_readcyclecounter(); es[1] += e1 - e0; e0 = e1; }
 #pragma unroll
         for (int k = 0; k < E::NIT; ++k) {
             const int prel = ((k * E::RPI) >> 5) * a.W + ((k * E::RPI) & 31);              // uniform
             u32x4 val = *reinterpret_cast<const u32x4*>(rd + k * E::RPI * E::ROW);
+            if (k == 1 && stamp) { unsigned long long e1 = __builtin_readcyclecounter(); es[2] += e1 - e0; e0 = e1; }
             if (rb) {
                 if constexpr (SZ == 4) {
                     f32x4 x = __builtin_bit_cast(f32x4, val), y = __builtin_bit_cast(f32x4, rr[k]);
@@ -784,6 +790,7 @@ __device__ __forceinline__ void epilogue_lds_fast(const f32x16 (&acc)[G::MT][NT]
             }
             *reinterpret_cast<u32x4*>(ob + (size_t)prel * pxs_o + vo_out) = val;
         }
+        if (stamp) { unsigned long long e1 = __builtin_readcyclecounter(); es[3] += e1 - e0; e0 = e1; }
     }
 }
 
@@ -888,7 +895,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
 
     const unsigned char* bl = smem_b + lane * 16;
     const bool stamp = (a.dbg & 64) && a.stamps;
-    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0}, ntile = 0;
+    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0}, ntile = 0, es[4] = {0, 0, 0, 0};
 #define SR_T() (stamp ? __builtin_readcyclecounter() : 0ull)
     for (;;) {
         const unsigned long long t_tile = SR_T();
@@ -995,11 +1002,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
         } else if (via_lds) {
             if constexpr (PL) {
                 __syncthreads();   // the tile's last chunk has been read by every wave: LDS becomes scratch
+                { unsigned long long tb = SR_T(); ts[4] += tb - t2; }
                 const bool interior = cur.y0 + G::TH <= H && cur.x0 + TW <= W &&
                                       (int)(blockIdx.y + 1) * NT * 32 <= a.cout_store && a.act != A_CLIP01;
                 if (interior) {
-                    if (a.out_f32) epilogue_lds_fast<G, NT, float>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem);
-                    else epilogue_lds_fast<G, NT, __bf16>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem);
+                    if (a.out_f32) epilogue_lds_fast<G, NT, float>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem, es, stamp);
+                    else epilogue_lds_fast<G, NT, __bf16>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem, es, stamp);
                 } else {
                     if (a.out_f32) epilogue_lds<G, NT, float, false>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem);
                     else epilogue_lds<G, NT, __bf16, false>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem);
@@ -1031,6 +1039,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
 #undef SR_T
     if (stamp && tid == 0) {
         for (int i = 0; i < 7; ++i) atomicAdd(a.stamps + i, ts[i]);
+        for (int i = 0; i < 4; ++i) atomicAdd(a.stamps + 8 + i, es[i]);
         atomicAdd(a.stamps + 7, ntile);
     }
 }

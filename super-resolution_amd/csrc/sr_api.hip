@@ -1154,6 +1154,8 @@ int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, in
         static const char* nm[8] = {"fetch_issue", "mfma_loop", "barrier1", "lds_store", "barrier2", "epilogue", "tile_total", "n"};
         double tot = (double)hs[6];
         for (int i = 0; i < 7; ++i) fprintf(stderr, "  stamp %-12s %6.1f %%  (%.0f cycles / tile / wave0)\n", nm[i], 100.0 * hs[i] / tot, (double)hs[i] / (double)hs[7]);
+        static const char* en[4] = {"epi.res_issue", "epi.lds_write", "epi.first_rd", "epi.add_store"};
+        for (int i = 0; i < 4; ++i) fprintf(stderr, "  stamp %-14s (%.0f cycles / tile / wave0)\n", en[i], (double)hs[8 + i] / (double)hs[7]);
     }
     return SR_OK;
 }
