@@ -78,12 +78,10 @@ __device__ __forceinline__ void mma_wx(f32x16& acc, const u32x4& w, const u32x4&
     else mma<PREC>(acc, x, w);
 }
 
-template <int PREC, int MODE, int NT, int STEPS, int MTC = 2, int NWV = 4>
+template <int PREC, int MODE, int NT, int STEPS, int MTC = 2>
 struct Geo {
-    static constexpr int NW = NWV;                            // waves per workgroup
-    static constexpr int NTH = NWV * 64;
     static constexpr int MT = MODE == M_CONV ? MTC : 1;      // 32-pixel row segments (tile rows) per wave
-    static constexpr int TH = NWV * MT;                       // tile rows
+    static constexpr int TH = 4 * MT;                         // tile rows
     static constexpr int HB = MODE == M_CONV ? 1 : 0;         // bottom / right halo
     static constexpr int HROWS = TH + 1 + HB, HCOLS = TW + 1 + HB;
     static constexpr int NPIX = HROWS * HCOLS;
@@ -94,7 +92,7 @@ struct Geo {
     static constexpr int ESZ = PREC == P_BF16 ? 2 : 4;        // bytes per activation element in HBM
     static constexpr int VPP = CKC * ESZ / 16;                // 16-B global vectors per pixel per chunk
     static constexpr int NV = NPIX * VPP;
-    static constexpr int ITER = (NV + NTH - 1) / NTH;
+    static constexpr int ITER = (NV + 255) / 256;
     static constexpr int BV = PREC == P_BF16X3 ? 2 : 1;       // B vectors per (step, N block): hi, lo
     static constexpr int AV = PREC == P_BF16X3 ? 2 : 1;       // A vectors per (step, M block): hi, lo
     static constexpr int STEPV = NT * BV * 64;                // 16-B vectors of packed weights per k-step
@@ -650,7 +648,7 @@ template <class G, int PREC>
 __device__ __forceinline__ void plan_init(StagePlan<G>& pl, int tid, int W, int px_bytes) {
 #pragma unroll
     for (int it = 0; it < G::ITER; ++it) {
-        const int v = tid + it * G::NTH;
+        const int v = tid + it * 256;
         const int p = v / G::VPP, part = v % G::VPP;
         const int py = p / G::HCOLS, px = p - py * G::HCOLS;
         pl.goff[it] = (unsigned)((py * W + px) * px_bytes + part * 16);
@@ -663,7 +661,7 @@ __device__ __forceinline__ unsigned tile_mask(int tid, int y0, int x0, int H, in
     unsigned mask = 0;
 #pragma unroll
     for (int it = 0; it < G::ITER; ++it) {   // once per tile: recomputing beats holding ITER more registers
-        const int v = tid + it * G::NTH;
+        const int v = tid + it * 256;
         const int p = v / G::VPP;
         const int py = p / G::HCOLS, px = p - py * G::HCOLS;
         const int gy = y0 - 1 + py, gx = x0 - 1 + px;
@@ -801,13 +799,13 @@ __device__ __forceinline__ void epilogue_lds_fast(const f32x16 (&acc)[G::MT][NT]
 // 32-channel N blocks) sit in LDS next to the halo tile, copied once per workgroup instead of being
 // streamed through the vector L1 by each of the 4 waves, so the MFMA loop issues only LDS reads.
 // The next chunk (halo tile + weights) is fetched into registers while the current one computes.
-template <int PREC, int NT, int STEPS, bool PL, int NWV = 4>
-__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv3x3_lds_kernel(const ConvArgs a) {
-    using G = Geo<PREC, M_CONV, NT, STEPS, 2, NWV>;
+template <int PREC, int NT, int STEPS, bool PL>
+__global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
+    using G = Geo<PREC, M_CONV, NT, STEPS>;
     constexpr int NSEG = 9 * STEPS;
     constexpr int NB = NT * G::BV;                       // weight vectors per lane per k-step
     constexpr int BVEC = NSEG * G::STEPV;                // 16-B weight vectors per chunk
-    constexpr int BITER = (BVEC + G::NTH - 1) / G::NTH;
+    constexpr int BITER = (BVEC + 255) / 256;
     constexpr int A_BYTES = G::TILE_BYTES * G::AV;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* smem_b = smem + A_BYTES;
@@ -835,15 +833,15 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv3x3_lds_kernel
 #pragma unroll
         for (int it = 0; it < BITER; ++it) {
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (BVEC % G::NTH == 0 || tid + it * G::NTH < BVEC) v = *reinterpret_cast<const u32x4*>(wb + it * (G::NTH * 16) + tid16);
+            if (BVEC % 256 == 0 || tid + it * 256 < BVEC) v = *reinterpret_cast<const u32x4*>(wb + it * 4096 + tid16);
             regs_b[it] = v;
         }
     };
     auto store_w = [&]() {
 #pragma unroll
         for (int it = 0; it < BITER; ++it)
-            if (BVEC % G::NTH == 0 || tid + it * G::NTH < BVEC)
-                *reinterpret_cast<u32x4*>(smem_b + it * (G::NTH * 16) + tid16) = regs_b[it];
+            if (BVEC % 256 == 0 || tid + it * 256 < BVEC)
+                *reinterpret_cast<u32x4*>(smem_b + it * 4096 + tid16) = regs_b[it];
     };
     struct TileXY {
         int b, y0, x0;
@@ -1154,14 +1152,14 @@ __global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) 
     tap_iter(std::integral_constant<int, 8>{});
 }
 
-size_t conv_lds_bytes(int prec, int mode, int nt, int steps, int mt, int nw) {
-    const int th = mode == M_CONV ? nw * mt : 4, hb = mode == M_CONV ? 1 : 0;
+size_t conv_lds_bytes(int prec, int mode, int nt, int steps, int mt) {
+    const int th = mode == M_CONV ? 4 * mt : 4, hb = mode == M_CONV ? 1 : 0;
     const size_t tile = (size_t)(th + 1 + hb) * (TW + 1 + hb) * (32 * steps + 16);
     const size_t a = prec == P_BF16X3 ? 2 * tile : tile;
     if (mode == M_CONVT) return a + (nt == 2 ? (size_t)2 * steps * nt * (prec == P_BF16X3 ? 2 : 1) * 1024 : 0);   // + two tap buffers
     const size_t bv = prec == P_BF16X3 ? 2 : 1;
     const size_t ab = a + (size_t)9 * steps * nt * bv * 1024;   // + the chunk's weights
-    const size_t scratch = (size_t)nw * 64 * (nt * 32 * 4 + 16);  // epilogue_lds, fp32 rows (the larger case)
+    const size_t scratch = (size_t)4 * 64 * (nt * 32 * 4 + 16);  // epilogue_lds, fp32 rows (the larger case)
     return ab > scratch ? ab : scratch;
 }
 
@@ -1178,7 +1176,7 @@ static int num_cus() {
 
 template <typename K>
 static hipError_t launch_k(K kernel, size_t lds, ConvArgs a, int th, int ncb, hipStream_t s, bool& attr_done,
-                           int wg_per_cu, int nth = 256) {
+                           int wg_per_cu) {
     if (lds > 64 * 1024 && !attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1194,7 +1192,7 @@ static hipError_t launch_k(K kernel, size_t lds, ConvArgs a, int th, int ncb, hi
         const int rounds = (per_xcd + max_slots - 1) / max_slots;
         gx = 8 * ((per_xcd + rounds - 1) / rounds);
     }
-    hipLaunchKernelGGL(kernel, dim3(gx, ncb), dim3(nth), lds, s, a);
+    hipLaunchKernelGGL(kernel, dim3(gx, ncb), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1202,25 +1200,17 @@ template <int PREC, int MODE, int NT, int STEPS>
 static hipError_t launch_one(const ConvArgs& a, int ncb, hipStream_t s) {
     static bool attr_done = false;
     if constexpr (MODE == M_CONV) {
-        if constexpr (NT == 2) {
-            static const int waves8 = getenv("SR_WAVES8") ? atoi(getenv("SR_WAVES8")) : 0;
-            if (waves8) {   // experiment: one 8-wave workgroup per CU on 16x32 tiles, weights fetched once per 512 pixels
-                static bool attr8 = false;
-                return launch_k(&conv3x3_lds_kernel<PREC, NT, STEPS, true, 8>, conv_lds_bytes(PREC, MODE, NT, STEPS, 2, 8), a,
-                                16, ncb, s, attr8, 1, 512);
-            }
-        }
-        return launch_k(&conv3x3_lds_kernel<PREC, NT, STEPS, true>, conv_lds_bytes(PREC, MODE, NT, STEPS, 2, 4), a, 8,
+        return launch_k(&conv3x3_lds_kernel<PREC, NT, STEPS, true>, conv_lds_bytes(PREC, MODE, NT, STEPS, 2), a, 8,
                         ncb, s, attr_done, 2);
     } else {
         if constexpr (NT == 2 && (STEPS * Geo<PREC, MODE, NT, STEPS>::STEPV) % 256 == 0) {
             if (a.nchunk == 1 && !(a.dbg & 128)) {
                 static bool attr2 = false;
-                return launch_k(&convT3x3_lds_kernel<PREC, STEPS>, conv_lds_bytes(PREC, MODE, NT, STEPS, 1, 4), a, 4, ncb, s,
+                return launch_k(&convT3x3_lds_kernel<PREC, STEPS>, conv_lds_bytes(PREC, MODE, NT, STEPS, 1), a, 4, ncb, s,
                                 attr2, 0);
             }
         }
-        return launch_k(&conv3x3_kernel<PREC, MODE, NT, STEPS>, conv_lds_bytes(PREC, MODE, NT, STEPS, 1, 4), a, 4, ncb,
+        return launch_k(&conv3x3_kernel<PREC, MODE, NT, STEPS>, conv_lds_bytes(PREC, MODE, NT, STEPS, 1), a, 4, ncb,
                         s, attr_done, 0);
     }
 }

@@ -60,7 +60,7 @@ hipError_t launch_conv(int prec, int mode, int nt, int steps, const ConvArgs& a,
 hipError_t launch_conv_tapsn(int prec, int nchunk, const ConvArgs& a, hipStream_t s);
 // out[y,x,co] = act(bias[co] + sum_tap P[y+ky-1, x+kx-1][tap*3+co]) (+ residual); a.in = P [B,H,W,32] fp32
 hipError_t launch_tap_gather(const ConvArgs& a, hipStream_t s);
-size_t conv_lds_bytes(int prec, int mode, int nt, int steps, int mt, int nw);
+size_t conv_lds_bytes(int prec, int mode, int nt, int steps, int mt);
 
 // element-wise / gather kernels (fused_ops.hip).  act_bf16: activations are bf16.
 hipError_t launch_fnet_input(const float* lr_t, const float* lr_tm1, void* out, int act_bf16,
