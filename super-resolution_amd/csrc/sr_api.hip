@@ -514,13 +514,22 @@ int run_fnet(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, float
 // SRNet: reference layers.py:66-76; input already concatenated into buf "s_in".
 // The LR-resolution trunk (head + 10 residual blocks) runs over sub-batches of `trunk_sub` clips so
 // that its two ping-pong activation tensors stay resident in the 256 MiB Infinity Cache between
-// layers instead of streaming through HBM 41 times per frame.
+// layers instead of streaming through HBM 41 times per frame (SR_TRUNK_SUB=n overrides the automatic
+// choice; a value >= the batch disables the split).
 int run_srnet(sr_ctx* c, int B, float* d_out) {
     const int P = c->prec, af = c->prec == P_BF16 ? 0 : 1;
     hipStream_t st = lane_st(c);
     const int H = c->h, W = c->w;
     const size_t es = af ? 4 : 2;
-    const int sub = c->trunk_sub > 0 ? c->trunk_sub : B;
+    // trunk sub-batch: the two ping-pong tensors of every lane in flight should stay inside the 256 MiB
+    // Infinity Cache with room for the rest of the traffic (measured: +3.5 % at 2 lanes x 2 clips)
+    int sub = c->prof_on ? B : c->trunk_sub;   // per-kernel timing: whole-batch launches, one lane
+    if (sub <= 0) {
+        const size_t img = (size_t)H * W * 64 * es;
+        const int lanes = c->lane_stream ? c->dual + 1 : 1;
+        sub = (int)std::max<size_t>(1, ((size_t)128 << 20) / ((size_t)lanes * 2 * img));
+    }
+    sub = std::min(sub, B);
     for (int b0 = 0; b0 < B; b0 += sub) {
         const int nb = b0 + sub <= B ? sub : B - b0;
         const size_t off = (size_t)b0 * H * W * 64 * es;
