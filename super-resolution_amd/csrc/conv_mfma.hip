@@ -310,66 +310,12 @@ __device__ __forceinline__ void epilogue_t(const f32x16 (&acc)[G::MT][NT], const
     }
 }
 
-// Channel-on-lane layout (pixels are the MFMA's A operand, weights its B operand): D has the output
-// channel on the lane (lane & 31) and 16 pixels (i&3) + 8(i>>2) + 4h in the registers, so one store
-// instruction writes two full 128-byte lines (32 consecutive fp32 channels of two pixels).
-template <class G, int MODE, int NT, typename OT>
-__device__ __forceinline__ void epilogue_cl(const f32x16 (&acc)[G::MT][NT], const ConvArgs& a, int pass, int b, int y0,
-                                            int x0, int wave, int r, int h) {
-    const int H = a.H, W = a.W;
-    const int OW = MODE == M_CONV ? W : 2 * W;
-    const int OH = MODE == M_CONV ? H : 2 * H;
-    const int act = a.act;
-    const float slope = (act == A_RELU || act == A_CLIP01) ? 0.f : (act == A_LRELU ? 0.2f : 1.f);
-    const float hi = act == A_CLIP01 ? 1.f : INFINITY;
-    constexpr int XS = MODE == M_CONV ? 1 : 2;   // output pixels per input pixel along x
-    OT* outp = reinterpret_cast<OT*>(a.out);
-    const OT* resp = reinterpret_cast<const OT*>(a.res);
-#pragma unroll
-    for (int m = 0; m < G::MT; ++m) {
-        int iy, oy;
-        if constexpr (MODE == M_CONV) {
-            iy = y0 + G::MT * wave + m;
-            oy = iy;
-        } else {
-            iy = y0 + wave;
-            oy = 2 * iy + (pass >> 1);
-        }
-        const int ox0 = XS * (x0 + 4 * h) + (MODE == M_CONV ? 0 : (pass & 1));
-        const size_t opix = ((size_t)b * OH + oy) * OW + ox0;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int co = (blockIdx.y * NT + n) * 32 + r;
-            const float bias = a.bias[co];
-            const bool cok = co < a.cout_store && iy < H;
-            OT* op = outp + opix * a.out_cs + co;
-            const OT* rp = resp ? resp + opix * a.res_cs + co : nullptr;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int px = (i & 3) + 8 * (i >> 2);           // + 4h, folded into ox0
-                if (cok && x0 + 4 * h + px < W) {
-                    float t = acc[m][n][i] + bias;
-                    t = t > 0.f ? t : t * slope;
-                    t = fminf(t, hi);
-                    if (act == A_TANH) t = tanh_fast(t);
-                    if (rp) t += (float)rp[(size_t)(XS * px) * a.res_cs];
-                    op[(size_t)(XS * px) * a.out_cs] = (OT)t;
-                }
-            }
-        }
-    }
-}
-
 template <class G, int MODE, int NT, bool PL, bool ADD_BIAS = true>
 __device__ __forceinline__ void epilogue(const f32x16 (&acc)[G::MT][NT], const ConvArgs& a, int pass, int b, int y0,
                                          int x0, int wave, int r, int h) {
-    if constexpr (PL) {
-        if (a.out_f32) epilogue_t<G, MODE, NT, float, ADD_BIAS>(acc, a, pass, b, y0, x0, wave, r, h);
-        else epilogue_t<G, MODE, NT, __bf16, ADD_BIAS>(acc, a, pass, b, y0, x0, wave, r, h);
-    } else {
-        if (a.out_f32) epilogue_cl<G, MODE, NT, float>(acc, a, pass, b, y0, x0, wave, r, h);
-        else epilogue_cl<G, MODE, NT, __bf16>(acc, a, pass, b, y0, x0, wave, r, h);
-    }
+    static_assert(PL, "only the pixel-on-lane operand order is built (the channel-on-lane epilogue was 2x slower)");
+    if (a.out_f32) epilogue_t<G, MODE, NT, float, ADD_BIAS>(acc, a, pass, b, y0, x0, wave, r, h);
+    else epilogue_t<G, MODE, NT, __bf16, ADD_BIAS>(acc, a, pass, b, y0, x0, wave, r, h);
 }
 
 // Transposed conv + tap projection of the FOLLOWING 3x3 conv with <= 3 output channels (SRNet:
