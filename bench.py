@@ -40,12 +40,43 @@ PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}   # MI355X_MICRO
 
 
 def make_inputs(rank):
-    """[FRAMES, CLIPS, 184, 320, 3] float32, rows 180..183 zero."""
-    from oracle import ref_numpy as rn   # synthetic-clip generator only (data, not compute)
+    """[FRAMES, CLIPS, 184, 320, 3] float32 in [0,1], rows 180..183 zero: per clip a smooth random
+    image (bilinear blow-up of coarse noise) drifting by a few pixels per frame, plus fine noise."""
     lr = np.zeros((FRAMES, CLIPS, H_PAD, W_LR, 3), np.float32)
     for c in range(CLIPS):
-        lr[:, c, :H_LR] = rn.synth_clip(rank * CLIPS + c, FRAMES, H_LR, W_LR)
+        rng = np.random.default_rng(1000 * rank + c)
+        coarse = rng.random((H_LR // 12 + 4, W_LR // 12 + 4, 3)).astype(np.float32)
+        big = np.kron(coarse, np.ones((12, 12, 1), np.float32))          # piecewise constant ...
+        k = np.ones(9, np.float32) / 9                                    # ... smoothed by a 9-tap box filter
+        big = np.apply_along_axis(lambda v: np.convolve(v, k, "same"), 0, big)
+        big = np.apply_along_axis(lambda v: np.convolve(v, k, "same"), 1, big)
+        dy, dx = rng.integers(-2, 3, 2)
+        for t in range(FRAMES):
+            oy, ox = 12 + dy * t % 12, 12 + dx * t % 12
+            frame = big[oy:oy + H_LR, ox:ox + W_LR] + 0.05 * rng.standard_normal((H_LR, W_LR, 3)).astype(np.float32)
+            lr[t, c, :H_LR] = np.clip(frame, 0.0, 1.0)
     return lr
+
+
+def make_weights(seed=7):
+    """Seeded random weights in the reference's tensor layout (76 Keras-named tensors; demo.h5 is
+    absent): Glorot-uniform kernels, small biases, the flow head scaled up and the last bias shifted
+    so that flows reach a few tenths of a pixel and outputs spread over [0,1]."""
+    import layers
+    rng = np.random.default_rng(seed)
+    out = {}
+    for i, (name, shape) in enumerate(layers.weight_specs()):
+        if len(shape) == 4:
+            limit = np.sqrt(6.0 / (9 * shape[2] + 9 * shape[3]))
+            w = rng.uniform(-limit, limit, size=shape)
+        else:
+            w = rng.uniform(-0.05, 0.05, size=shape)
+        if i == 26:
+            w = w * 8.0
+        if i == 75:
+            w = w + 0.45
+        out[name] = w.astype(np.float32)
+    return out
 
 
 def run_steps(ctx, lr_dev, n, t0_frame=0):
@@ -106,7 +137,7 @@ def pmc_traffic(dtype):
 def cpu_baseline(weights, lr):
     """The torch-CPU restatement (oracle/ref_torch.py; kind 'port': the reference's
     TF1/Keras path cannot run here) on a bounded sample: 1 clip, 1 warm-up + 3 timed
-    frames at 184x320."""
+    frames at 184x320.  The only place where bench.py touches oracle/."""
     import torch
     from oracle import ref_torch as rt
     tw = rt.TorchWeights(weights)
@@ -154,8 +185,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import sr_hip
-    from oracle import ref_numpy as rn
-    weights = rn.make_weights(7)          # seeded random init in the demo.h5 tensor layout (demo.h5 is absent)
+    weights = make_weights(7)
     lr = make_inputs(rank)
     lr_dev = torch.from_numpy(lr).cuda()
     stream = torch.cuda.current_stream().cuda_stream
