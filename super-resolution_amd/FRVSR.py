@@ -7,10 +7,10 @@ context (libsr_hip.so), reachable through the same attributes:
 
 eval() keeps the reference's recurrent driver semantics (FRVSR.py:231-234, 280-309):
 rows x cols independent tiles batched through one step, zero initial state, estimate
-state := output, previous LR := current tiles, timing bracket around the step, PSNR
-every 10th frame, ``metrics.txt`` with the reference's columns.  Differences, on purpose
+state := output, previous LR := current tiles, timing bracket around the step, PSNR and
+SSIM every 10th frame, ``metrics.txt`` with the reference's columns.  Differences, on purpose
 (SURVEY.md Appendix B): state is reset per clip, the mean PSNR divides by the number of
-samples actually summed, clips are .npy arrays (video decode / SSIM / YOLO are out of scope).
+samples actually summed, clips are .npy arrays (video decode / YOLO are out of scope).
 """
 import datetime
 import os
@@ -19,7 +19,7 @@ import numpy as np
 
 from layers import (FNet, GeneratorCore, GeneratorModel, Space2Depth, SRNet, Upscaling, Warp)
 from utils import (box_downscale, denormalize, get_videos, load_clip, merge_tiles, normalize, psnr,
-                   shard_range, split_tiles)
+                   shard_range, split_tiles, ssim)
 
 
 class FrameRecurrentVideoSR(object):
@@ -76,7 +76,7 @@ class FrameRecurrentVideoSR(object):
     # ------------------------------------------------------------------ evaluation
     def super_resolve_clip(self, lr_frames, hr_frames=None, name='clip', metrics_file=None):
         """lr_frames [T, rows*h, cols*w, 3] float32 in [0,1] -> estimated [T, rows*4h, cols*4w, 3].
-        Returns (frames, stats) with stats = dict(psnr=[...every 10th frame...], ms=[...per frame...])."""
+        Returns (frames, stats) with stats = dict(psnr=[...], ssim=[...] (every 10th frame), ms=[...per frame...])."""
         rows = int(self.configs['data'].get('rows', 1))
         cols = int(self.configs['data'].get('cols', 1))
         h, w, _ = self.lr_shape
@@ -86,7 +86,7 @@ class FrameRecurrentVideoSR(object):
         gen = self._generator()
         gen.clip_begin(rows * cols)            # zero state for prev LR tiles and prev estimates
         out = np.empty((T, rows * 4 * h, cols * 4 * w, 3), np.float32)
-        stats = {'psnr': [], 'ms': []}
+        stats = {'psnr': [], 'ssim': [], 'ms': []}
         for t in range(T):
             tiles = split_tiles(lr_frames[t], rows, cols, h, w)
             t0 = datetime.datetime.now()
@@ -96,9 +96,12 @@ class FrameRecurrentVideoSR(object):
             stats['ms'].append(ms)
             if t % 10 == 0 and hr_frames is not None:
                 p = psnr(hr_frames[t], out[t])
+                q = ssim(hr_frames[t], out[t])
                 stats['psnr'].append(p)
-                if metrics_file is not None:
-                    metrics_file.write('Video:\t%s\tFrame:\t%d\tInference time:\t%d\tPSNR:\t%f\n' % (name, t, ms, p))
+                stats['ssim'].append(q)
+                if metrics_file is not None:    # the reference's row (FRVSR.py:339)
+                    metrics_file.write('Video:\t%s\tFrame:\t%d\tInference time:\t%d\tPSNR:\t%f\tSSIM:\t%f\n'
+                                       % (name, t, ms, p, q))
         return out, stats
 
     def eval(self):
@@ -112,7 +115,7 @@ class FrameRecurrentVideoSR(object):
         rows = int(self.configs['data'].get('rows', 1))
         cols = int(self.configs['data'].get('cols', 1))
         H, W = self.hr_shape[0] * rows, self.hr_shape[1] * cols
-        total, n = 0.0, 0
+        total, total_ssim, n = 0.0, 0.0, 0
         with open(os.path.join(out_dir, 'metrics.txt' if world == 1 else 'metrics_rank%d.txt' % rank), 'w+') as f:
             for path in clips[lo:hi]:
                 clip = load_clip(path)
@@ -123,12 +126,14 @@ class FrameRecurrentVideoSR(object):
                 est, stats = self.super_resolve_clip(lr, hr, os.path.basename(path), f)
                 np.save(os.path.join(out_dir, os.path.basename(path)), denormalize(est))
                 total += sum(stats['psnr'])
+                total_ssim += sum(stats['ssim'])
                 n += len(stats['psnr'])
                 f.write('\n')
                 print('[INFO] %s: %d frames, FRVSR inference %.2f ms/frame, PSNR %.3f' % (
                     os.path.basename(path), len(est), float(np.mean(stats['ms'])),
                     float(np.mean(stats['psnr'])) if stats['psnr'] else float('nan')))
             mean_psnr = total / n if n else float('nan')
-            f.write('Total PSNR:\t%f' % mean_psnr)
-        print('\n[INFO] Avg. FRVSR PSNR: %f' % mean_psnr)
+            mean_ssim = total_ssim / n if n else float('nan')
+            f.write('Total PSNR:\t%f\tTotal SSIM:\t%f' % (mean_psnr, mean_ssim))    # FRVSR.py:368
+        print('\n[INFO] Avg. FRVSR PSNR: %f\tAvg. FRVSR SSIM: %f' % (mean_psnr, mean_ssim))
         return mean_psnr

@@ -1,9 +1,11 @@
 """Host helpers of the drop-in API (reference utils.py:24-71).
 
 normalize / denormalize / psnr keep the reference's exact numpy semantics (PSNR is the
-parity metric of BASELINE.json).  Video decoding (cv2), SSIM (scikit-image) and the VGG /
-YOLO metrics are third-party and out of scope of this path: clips are
-numpy arrays here.
+parity metric of BASELINE.json).  ssim restates what the reference's call computes (cv2 gray
+conversion + scikit-image 0.14 ``compare_ssim`` defaults) with numpy / scipy, because neither
+package is installed here: PARITY UNPINNED against the real packages.  Video decoding (cv2) and
+the VGG / YOLO metrics are third-party and out of scope of this path:
+clips are numpy arrays here.
 """
 import math
 import os
@@ -50,6 +52,32 @@ def psnr(img1, img2):
         return 100
     pixel_max = 1.0
     return 20 * math.log10(pixel_max / math.sqrt(mse))
+
+
+def ssim(img1, img2):
+    """Mean structural similarity as reference utils.py:74-77 computes it:
+    ``cv2.cvtColor(img.astype('Float32'), COLOR_BGR2GRAY)`` (Y = 0.114 B + 0.587 G + 0.299 R) on both
+    images, then ``skimage.measure.compare_ssim(a, b, full=True)[0]`` with its defaults: 7x7 uniform
+    window (scipy ``uniform_filter``, reflect borders), sample covariance (N/(N-1)), K1 = 0.01,
+    K2 = 0.03, data_range = 2 (skimage takes the dtype range (-1, 1) of a float image when none is
+    given), mean over the image cropped by 3 pixels per side."""
+    from scipy.ndimage import uniform_filter
+    if img1.shape != img2.shape or img1.ndim != 3 or img1.shape[2] != 3:
+        raise ValueError('ssim expects two [H,W,3] BGR images of the same shape')
+    if min(img1.shape[:2]) < 7:
+        raise ValueError('win_size exceeds image extent')       # skimage's own error
+    coef = np.array([0.114, 0.587, 0.299], np.float32)
+    x = (img1.astype(np.float32) @ coef).astype(np.float64)
+    y = (img2.astype(np.float32) @ coef).astype(np.float64)
+    win, data_range = 7, 2.0
+    cov_norm = win * win / (win * win - 1.0)
+    ux, uy = uniform_filter(x, size=win), uniform_filter(y, size=win)
+    uxx, uyy, uxy = uniform_filter(x * x, size=win), uniform_filter(y * y, size=win), uniform_filter(x * y, size=win)
+    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2))
+    pad = (win - 1) // 2
+    return float(s[pad:-pad, pad:-pad].mean())
 
 
 def box_downscale(hr, scale=4):

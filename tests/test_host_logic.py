@@ -118,6 +118,34 @@ def test_utils_semantics():
     assert abs(utils.psnr(a, a + 0.1) - rn.psnr(a, a + 0.1)) < 1e-12
 
 
+def test_ssim_restatement():
+    """utils.ssim restates cv2 gray + skimage-0.14 compare_ssim defaults (reference utils.py:74-77);
+    neither package is installed, so this is a definition-level check (PARITY UNPINNED): identical
+    images give 1, the value equals a direct windowed evaluation of the SSIM formula with
+    reflect-padded 7x7 windows, sample covariance, data_range 2, borders cropped by 3."""
+    import utils
+    rng = np.random.default_rng(3)
+    a = rng.random((12, 15, 3)).astype(np.float32)
+    b = np.clip(a + 0.1 * rng.standard_normal(a.shape).astype(np.float32), 0, 1)
+    assert abs(utils.ssim(a, a) - 1.0) < 1e-12
+    coef = np.array([0.114, 0.587, 0.299])
+    x, y = a.astype(np.float64) @ coef, b.astype(np.float64) @ coef
+    c1, c2 = (0.01 * 2) ** 2, (0.03 * 2) ** 2
+    vals = []
+    for i in range(3, 12 - 3):          # windows fully inside: the reflect padding never matters after the crop
+        for j in range(3, 15 - 3):
+            wx, wy = x[i - 3:i + 4, j - 3:j + 4].ravel(), y[i - 3:i + 4, j - 3:j + 4].ravel()
+            mx, my = wx.mean(), wy.mean()
+            vx, vy = wx.var(ddof=1), wy.var(ddof=1)
+            vxy = ((wx - mx) * (wy - my)).sum() / 48
+            vals.append((2 * mx * my + c1) * (2 * vxy + c2) / ((mx * mx + my * my + c1) * (vx + vy + c2)))
+    got = utils.ssim(a, b)
+    assert abs(got - np.mean(vals)) < 1e-6
+    assert 0 < got < 1
+    with pytest.raises(ValueError):
+        utils.ssim(a[:5], b[:5])
+
+
 def test_tiling_roundtrip_and_order():
     frame = np.arange(2 * 4 * 3 * 6 * 3, dtype=np.float32).reshape(8, 18, 3)
     tiles = utils.split_tiles(frame, 2, 3, 4, 6)
