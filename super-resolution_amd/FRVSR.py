@@ -18,7 +18,7 @@ import os
 import numpy as np
 
 from layers import (FNet, GeneratorCore, GeneratorModel, Space2Depth, SRNet, Upscaling, Warp)
-from utils import (box_downscale, denormalize, get_videos, load_clip, merge_tiles, normalize, psnr,
+from utils import (blur_cubic_downscale, box_downscale, denormalize, get_videos, load_clip, merge_tiles, normalize, psnr,
                    shard_range, split_tiles, ssim)
 
 
@@ -122,7 +122,9 @@ class FrameRecurrentVideoSR(object):
                 hr = normalize(clip) if clip.dtype == np.uint8 else clip.astype(np.float32)
                 if hr.shape[1:3] != (H, W):
                     raise ValueError(f'{path}: frames are {hr.shape[1:3]}, the configured HR canvas is {(H, W)}')
-                lr = box_downscale(hr, 4)
+                # the reference's LR synthesis (FRVSR.py:274-277); data.lr_synthesis: box selects a plain average
+                synth = str(self.configs['data'].get('lr_synthesis', 'blur_cubic'))
+                lr = box_downscale(hr, 4) if synth == 'box' else blur_cubic_downscale(hr)
                 est, stats = self.super_resolve_clip(lr, hr, os.path.basename(path), f)
                 np.save(os.path.join(out_dir, os.path.basename(path)), denormalize(est))
                 total += sum(stats['psnr'])

@@ -80,6 +80,31 @@ def ssim(img1, img2):
     return float(s[pad:-pad, pad:-pad].mean())
 
 
+def blur_cubic_downscale(hr):
+    """HR -> LR as the reference synthesises its inputs (FRVSR.py:274-277): ``cv2.GaussianBlur(hr,
+    (5, 5), 0)`` followed by ``cv2.resize(..., INTER_CUBIC)`` to a quarter of the size, restated with
+    numpy because OpenCV is not installed (PARITY UNPINNED against cv2):
+    * sigma 0 with a 5-tap kernel selects OpenCV's fixed table [1, 4, 6, 4, 1] / 16, borders
+      BORDER_REFLECT_101;
+    * an exact x4 reduction samples at source coordinate 4d + 1.5, i.e. the four pixels of each block
+      of 4 with the cubic (a = -0.75) weights of phase 0.5: [-3, 19, 19, -3] / 32, no border cases.
+    hr: [T, H, W, 3] float32 with H, W multiples of 4."""
+    T, H, W, C = hr.shape
+    if H % 4 or W % 4:
+        raise ValueError('HR height and width must be multiples of 4')
+    g = np.array([1, 4, 6, 4, 1], np.float32) / 16
+    k = np.array([-3, 19, 19, -3], np.float32) / 32
+    x = hr.astype(np.float32)
+    for axis, n in ((1, H), (2, W)):
+        pad = [(0, 0)] * 4
+        pad[axis] = (2, 2)
+        xp = np.pad(x, pad, mode='reflect')                     # reflect without repeating the edge = REFLECT_101
+        x = sum(g[i] * np.take(xp, np.arange(i, i + n), axis=axis) for i in range(5))
+    x = np.tensordot(x.reshape(T, H // 4, 4, W, C), k, axes=([2], [0]))            # rows
+    x = np.tensordot(x.reshape(T, H // 4, W // 4, 4, C), k, axes=([3], [0]))       # columns
+    return x.astype(np.float32)
+
+
 def box_downscale(hr, scale=4):
     """HR -> LR stand-in for the reference's GaussianBlur + cubic resize (cv2, FRVSR.py:274-277):
     a plain scale x scale box average.  Used only to synthesise LR inputs from HR clips."""

@@ -146,6 +146,27 @@ def test_ssim_restatement():
         utils.ssim(a[:5], b[:5])
 
 
+def test_blur_cubic_downscale_kats():
+    """Restatement of cv2.GaussianBlur(5x5, sigma 0) + cv2.resize(INTER_CUBIC) x1/4 (reference
+    FRVSR.py:274-277; OpenCV absent: parity unpinned).  Constants are preserved, an impulse spreads
+    with the separable product of the [1,4,6,4,1]/16 and [-3,19,19,-3]/32 kernels."""
+    import utils
+    c = np.full((1, 16, 24, 3), 0.37, np.float32)
+    np.testing.assert_allclose(utils.blur_cubic_downscale(c), 0.37, atol=1e-6)
+    imp = np.zeros((1, 16, 16, 3), np.float32)
+    imp[0, 9, 6, 1] = 1.0
+    out = utils.blur_cubic_downscale(imp)
+    assert out.shape == (1, 4, 4, 3)
+    g, k = np.array([1, 4, 6, 4, 1]) / 16, np.array([-3, 19, 19, -3]) / 32
+    def resp(pos):          # 1-D response of output d to an impulse at pos
+        b = np.zeros(16 + 4); b[pos:pos + 5] = g; b = b[2:-2]            # blurred impulse (interior: no border)
+        return np.array([b[4 * d:4 * d + 4] @ k for d in range(4)])
+    np.testing.assert_allclose(out[0, :, :, 1], np.outer(resp(9), resp(6)), atol=1e-7)
+    assert out[..., 0].max() == 0 and out[..., 2].max() == 0          # channels stay separate
+    with pytest.raises(ValueError):
+        utils.blur_cubic_downscale(np.zeros((1, 6, 8, 3), np.float32))
+
+
 def test_tiling_roundtrip_and_order():
     frame = np.arange(2 * 4 * 3 * 6 * 3, dtype=np.float32).reshape(8, 18, 3)
     tiles = utils.split_tiles(frame, 2, 3, 4, 6)
