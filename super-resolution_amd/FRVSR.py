@@ -18,7 +18,7 @@ import os
 import numpy as np
 
 from layers import (FNet, GeneratorCore, GeneratorModel, Space2Depth, SRNet, Upscaling, Warp)
-from utils import (blur_cubic_downscale, box_downscale, denormalize, get_videos, load_clip, merge_tiles, normalize, psnr,
+from utils import (blur_cubic_downscale, box_downscale, cubic_upscale4, denormalize, get_videos, load_clip, merge_tiles, normalize, psnr,
                    shard_range, split_tiles, ssim)
 
 
@@ -86,7 +86,7 @@ class FrameRecurrentVideoSR(object):
         gen = self._generator()
         gen.clip_begin(rows * cols)            # zero state for prev LR tiles and prev estimates
         out = np.empty((T, rows * 4 * h, cols * 4 * w, 3), np.float32)
-        stats = {'psnr': [], 'ssim': [], 'ms': []}
+        stats = {'psnr': [], 'ssim': [], 'bic_psnr': [], 'bic_ssim': [], 'ms': []}
         for t in range(T):
             tiles = split_tiles(lr_frames[t], rows, cols, h, w)
             t0 = datetime.datetime.now()
@@ -99,6 +99,9 @@ class FrameRecurrentVideoSR(object):
                 q = ssim(hr_frames[t], out[t])
                 stats['psnr'].append(p)
                 stats['ssim'].append(q)
+                bic = cubic_upscale4(lr_frames[t:t + 1])[0]    # the reference's bicubic baseline (FRVSR.py:304,322,328)
+                stats['bic_psnr'].append(psnr(bic, hr_frames[t]))
+                stats['bic_ssim'].append(ssim(bic, hr_frames[t]))
                 if metrics_file is not None:    # the reference's row (FRVSR.py:339)
                     metrics_file.write('Video:\t%s\tFrame:\t%d\tInference time:\t%d\tPSNR:\t%f\tSSIM:\t%f\n'
                                        % (name, t, ms, p, q))
@@ -115,7 +118,7 @@ class FrameRecurrentVideoSR(object):
         rows = int(self.configs['data'].get('rows', 1))
         cols = int(self.configs['data'].get('cols', 1))
         H, W = self.hr_shape[0] * rows, self.hr_shape[1] * cols
-        total, total_ssim, n = 0.0, 0.0, 0
+        total, total_ssim, total_bic, total_bic_ssim, n = 0.0, 0.0, 0.0, 0.0, 0
         with open(os.path.join(out_dir, 'metrics.txt' if world == 1 else 'metrics_rank%d.txt' % rank), 'w+') as f:
             for path in clips[lo:hi]:
                 clip = load_clip(path)
@@ -129,6 +132,8 @@ class FrameRecurrentVideoSR(object):
                 np.save(os.path.join(out_dir, os.path.basename(path)), denormalize(est))
                 total += sum(stats['psnr'])
                 total_ssim += sum(stats['ssim'])
+                total_bic += sum(stats['bic_psnr'])
+                total_bic_ssim += sum(stats['bic_ssim'])
                 n += len(stats['psnr'])
                 f.write('\n')
                 print('[INFO] %s: %d frames, FRVSR inference %.2f ms/frame, PSNR %.3f' % (
@@ -137,5 +142,8 @@ class FrameRecurrentVideoSR(object):
             mean_psnr = total / n if n else float('nan')
             mean_ssim = total_ssim / n if n else float('nan')
             f.write('Total PSNR:\t%f\tTotal SSIM:\t%f' % (mean_psnr, mean_ssim))    # FRVSR.py:368
+            if n:                                                                     # FRVSR.py:369, typo included
+                f.write('Total bicubuc PSNR:\t%f\tTotal bicubic SSIM:\t%f' % (total_bic / n, total_bic_ssim / n))
+                print('\n[INFO] Avg. Bicubic PSNR: %f\tAvg. Bicubic SSIM: %f' % (total_bic / n, total_bic_ssim / n))
         print('\n[INFO] Avg. FRVSR PSNR: %f\tAvg. FRVSR SSIM: %f' % (mean_psnr, mean_ssim))
         return mean_psnr

@@ -105,6 +105,36 @@ def blur_cubic_downscale(hr):
     return x.astype(np.float32)
 
 
+def cubic_upscale4(lr):
+    """LR -> HR bicubic baseline of the reference's metrics (FRVSR.py:304-305): ``cv2.resize(lr, 4x,
+    INTER_CUBIC)`` restated with numpy (OpenCV absent: PARITY UNPINNED).  Destination pixel d samples
+    the source at (d + 0.5) / 4 - 0.5 with the 4-tap cubic kernel, a = -0.75; taps outside the image
+    are clamped to the border pixel (OpenCV's resize replicates edges).  lr: [T, h, w, 3] float."""
+    a = -0.75
+
+    def weights(t):
+        return np.array([((a * (t + 1) - 5 * a) * (t + 1) + 8 * a) * (t + 1) - 4 * a,
+                         ((a + 2) * t - (a + 3)) * t * t + 1,
+                         ((a + 2) * (1 - t) - (a + 3)) * (1 - t) * (1 - t) + 1,
+                         0.0])
+
+    x = lr.astype(np.float32)
+    for axis in (1, 2):
+        n = x.shape[axis]
+        src = (np.arange(4 * n) + 0.5) / 4 - 0.5
+        i0 = np.floor(src).astype(np.int64)
+        w = np.stack([weights(t) for t in (src - i0)], 0)
+        w[:, 3] = 1.0 - w[:, :3].sum(1)                        # OpenCV computes the last tap as the remainder
+        out = 0
+        for k in range(4):
+            idx = np.clip(i0 - 1 + k, 0, n - 1)
+            shape = [1, 1, 1, 1]
+            shape[axis] = 4 * n
+            out = out + np.take(x, idx, axis=axis) * w[:, k].astype(np.float32).reshape(shape)
+        x = out
+    return x.astype(np.float32)
+
+
 def box_downscale(hr, scale=4):
     """HR -> LR stand-in for the reference's GaussianBlur + cubic resize (cv2, FRVSR.py:274-277):
     a plain scale x scale box average.  Used only to synthesise LR inputs from HR clips."""

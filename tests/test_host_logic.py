@@ -167,6 +167,35 @@ def test_blur_cubic_downscale_kats():
         utils.blur_cubic_downscale(np.zeros((1, 6, 8, 3), np.float32))
 
 
+def test_cubic_upscale4_kats():
+    """Restatement of cv2.resize(x4, INTER_CUBIC) (reference FRVSR.py:304; OpenCV absent: parity
+    unpinned): constants are reproduced, a ramp and an impulse come out with the hand-evaluated weights
+    of the a = -0.75 kernel (which, unlike a = -0.5, does not reproduce linear ramps exactly)."""
+    import utils
+    c = np.full((1, 5, 6, 3), 0.25, np.float32)
+    np.testing.assert_allclose(utils.cubic_upscale4(c), 0.25, atol=1e-6)
+    ramp = np.tile(np.arange(8, dtype=np.float32)[None, None, :, None], (1, 4, 1, 3))
+    up = utils.cubic_upscale4(ramp)
+    assert up.shape == (1, 16, 32, 3)
+    # destination 8 samples source 1.625: taps on pixels 0..3 with phase t = 0.625
+    a, t = -0.75, 0.625
+    c0 = ((a * (t + 1) - 5 * a) * (t + 1) + 8 * a) * (t + 1) - 4 * a
+    c1 = ((a + 2) * t - (a + 3)) * t * t + 1
+    c2 = ((a + 2) * (1 - t) - (a + 3)) * (1 - t) * (1 - t) + 1
+    c3 = 1 - c0 - c1 - c2
+    assert abs(up[0, 5, 8, 0] - (0 * c0 + 1 * c1 + 2 * c2 + 3 * c3)) < 1e-5
+    assert abs(up[0, 5, 8, 0] - 1.595703) < 1e-5
+    # left border: destination 0 samples source -0.375 -> taps -2..1 clamped to pixel 0, 0, 0, 1
+    t = 0.625
+    assert abs(up[0, 0, 0, 0] - (1 * c3)) < 1e-5
+    imp = np.zeros((1, 1, 9, 3), np.float32)
+    imp[0, 0, 4, 0] = 1
+    # destination 18 samples source 4.125: tap weights of phase 0.125 around pixel 4
+    t = 0.125
+    w1 = ((-0.75 + 2) * t - (-0.75 + 3)) * t * t + 1
+    assert abs(utils.cubic_upscale4(imp)[0, 0, 18, 0] - w1) < 1e-6
+
+
 def test_tiling_roundtrip_and_order():
     frame = np.arange(2 * 4 * 3 * 6 * 3, dtype=np.float32).reshape(8, 18, 3)
     tiles = utils.split_tiles(frame, 2, 3, 4, 6)
