@@ -90,6 +90,37 @@ def test_conv3x3_few_outputs(sh, dtype, tol, B, H, W, Cin, Cout):
     assert np.abs(got - (rn.clip01(want) + res)).max() <= tol
 
 
+def test_conv_random_shape_sweep(sh):
+    """Seeded sweep over ragged shapes, channel counts around the 16 / 32 / 64 boundaries, activations,
+    residuals and the three precisions: conv and transposed conv against the fp64 numpy oracle."""
+    rng = np.random.default_rng(1234)
+    tol = {"fp32": 3e-5, "bf16x3": 3e-4, "bf16": 8e-2}
+    for case in range(24):
+        B = int(rng.integers(1, 4))
+        H, W = int(rng.integers(1, 41)), int(rng.integers(1, 71))
+        Cin = int(rng.choice([1, 3, 15, 16, 17, 31, 32, 33, 48, 64, 65, 96, 128]))
+        Cout = int(rng.choice([1, 2, 3, 4, 16, 31, 32, 33, 64, 65, 96]))
+        dtype = ["fp32", "bf16x3", "bf16"][case % 3]
+        x = rnd(100 + case, B, H, W, Cin)
+        b = rnd(300 + case, Cout, lo=-0.5, hi=0.5)
+        if case % 4 == 3:      # transposed conv: Keras kernel layout (kh, kw, out, in)
+            w = rnd(200 + case, 3, 3, Cout, Cin, lo=-0.1, hi=0.1)
+            want = rn.relu(rn.conv_transpose3x3_s2_same(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64)))
+            got = sh.conv_transpose3x3_s2(x, w, b, act="relu", dtype=dtype)
+        else:
+            w = rnd(200 + case, 3, 3, Cin, Cout, lo=-0.1, hi=0.1)
+            act = ["none", "relu", "lrelu"][case % 3]
+            res = rnd(400 + case, B, H, W, Cout) if case % 2 else None
+            want = rn.conv3x3_same(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+            want = {"none": lambda v: v, "relu": rn.relu, "lrelu": rn.leaky_relu}[act](want)
+            if res is not None:
+                want = want + res
+            got = sh.conv3x3(x, w, b, act=act, res=res, dtype=dtype)
+        assert got.shape == want.shape, (case, got.shape, want.shape)
+        err = np.abs(got - want).max()
+        assert err <= tol[dtype] * max(1.0, np.abs(want).max()), (case, dtype, B, H, W, Cin, Cout, err)
+
+
 CONVT_CASES = [(1, 8, 32, 64, 64), (2, 4, 8, 16, 64), (1, 5, 7, 3, 5), (1, 16, 40, 64, 64), (1, 1, 1, 2, 3)]
 
 

@@ -55,6 +55,20 @@ def test_golden_step16_all_intermediates(sh, weights7):
     ctx.close()
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("h,w,B", [(8, 104, 3), (72, 24, 2), (16, 40, 5)])
+def test_step_ragged_shapes_and_odd_batches(sh, weights7, h, w, B, dtype):
+    """Widths that are not multiples of the 32-pixel tile, heights below / above one tile, batches that
+    split unevenly over the two lanes and the trunk sub-batches."""
+    lr_t, lr_tm1, est = step_inputs(500 + h + w, B, h, w)
+    want, want_lw = rt.generator_step(weights7, lr_t, lr_tm1, est)
+    ctx = make_ctx(sh, weights7, h, w, B, dtype=dtype)
+    got, lw = ctx.step(lr_t, lr_tm1, est)
+    ctx.close()
+    assert np.abs(got - want).max() <= FP32_TOL
+    assert np.abs(lw - want_lw).max() <= FP32_TOL
+
+
 @pytest.mark.parametrize("h,w,B", [(24, 40, 1), (64, 64, 2), (8, 8, 3), (40, 72, 1)])
 def test_step_vs_oracle_fp32(sh, weights7, h, w, B):
     lr_t, lr_tm1, est = step_inputs(200 + h, B, h, w)
