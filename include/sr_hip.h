@@ -149,6 +149,50 @@ int sr_op_warp(int device, int B, int H, int W, int C, const float* img, const f
 /* tf.space_to_depth(x, bs): reference layers.py:109.  out (B,H/bs,W/bs,bs*bs*C). */
 int sr_op_space_to_depth(int device, int B, int H, int W, int C, int bs, const float* x, float* out);
 
+/* ---- training step (SURVEY.md section 8 f, rank 1) ------------------------------------------------
+ * Replaces frvsr.train_on_batch([lr_t, lr_tm1, est_tm1], [hr_t, lr_t]) (reference FRVSR.py:154-156)
+ * on the model compiled at FRVSR.py:69-71: loss = 1 * mean((I_est_t - hr_t)^2) + 1 * mean((I_LR_est_t_1
+ * - lr_t)^2) (Keras mean_squared_error = mean over every element), optimizer Adam(lr) with Keras
+ * 2.2.4 defaults (beta_1 0.9, beta_2 0.999, epsilon 1e-7, lr_t = lr*sqrt(1-beta_2^t)/(1-beta_1^t)).
+ * prev-LR and prev-estimate are constant inputs (no gradient through time, FRVSR.py:140-151); the
+ * warps are differentiated with respect to the flow only.  ctx dtype must be fp32 or bf16x3, model
+ * SR_FRVSR.  losses[3] = {total, sr_loss, flow_loss} (Keras train_on_batch order, FRVSR.py:161).
+ *
+ * sr_train_grads: forward + backward of one batch (host pointers; _dev: device pointers); the
+ *   gradient of all 76 tensors lands in one flat fp32 device vector in file order (kernel then
+ *   bias per layer, Keras layouts) and, if d_grads != NULL, is copied to that DEVICE buffer of
+ *   sr_train_param_count() floats -- the buffer a data-parallel job all-reduces (RCCL) before
+ * sr_train_apply: Adam step from d_grads * grad_scale (NULL: the ctx's own gradient vector) on the
+ *   device master weights, then re-pack of every MFMA weight buffer on the device; the next
+ *   sr_step / sr_clip_push and sr_get_tensor (save_weights) see the updated weights.
+ * sr_train_on_batch = sr_train_grads + sr_train_apply with the Keras defaults (single GPU). */
+int sr_train_param_count(const sr_ctx* ctx, int64_t* n);
+int sr_train_grads(sr_ctx* ctx, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1,
+                   const float* hr_t, float* d_grads, float* losses);
+int sr_train_grads_dev(sr_ctx* ctx, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1,
+                       const float* hr_t, float* d_grads, float* losses);
+int sr_train_read_grads(sr_ctx* ctx, float* host_out);
+int sr_train_apply(sr_ctx* ctx, const float* d_grads, float grad_scale, float lr, float beta1,
+                   float beta2, float eps);
+int sr_train_on_batch(sr_ctx* ctx, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1,
+                      const float* hr_t, float lr, float* losses);
+int64_t sr_train_iterations(const sr_ctx* ctx);   /* optimizer steps taken (Keras `iterations`) */
+
+/* Gradients of the single ops (host pointers, NHWC float32), for the parity tests against autograd:
+ * Conv2D 3x3 'same' (x, w HWIO, dy) -> dx (nullable), dw (3,3,Cin,Cout), db (nullable);
+ * Conv2DTranspose 3x3 s2 (x (B,H,W,Cin), w (3,3,Cout,Cin), dy (B,2H,2W,Cout)) -> dx, dw, db
+ *   (dx needs Cout % 64 == 0, the layers of reference layers.py:71-74);
+ * MaxPool2D 2x2 'same' (first maximum takes the gradient); legacy bilinear resize (adjoint);
+ * dense_image_warp with respect to the flow. */
+int sr_op_conv3x3_bwd(int device, int dtype, int B, int H, int W, int Cin, int Cout, const float* x,
+                      const float* w, const float* dy, float* dx, float* dw, float* db);
+int sr_op_convT3x3s2_bwd(int device, int B, int H, int W, int Cin, int Cout, const float* x,
+                         const float* w, const float* dy, float* dx, float* dw, float* db);
+int sr_op_maxpool2_bwd(int device, int B, int H, int W, int C, const float* x, const float* gy, float* gx);
+int sr_op_resize_bilinear_bwd(int device, int B, int H, int W, int C, int s, const float* gy, float* gx);
+int sr_op_warp_bwd_flow(int device, int B, int H, int W, int C, const float* img, const float* flow,
+                        const float* g, float* gflow);
+
 /* Measurement utility (no reference counterpart): times `iters` back-to-back launches
  * of one 3x3 conv (or stride-2 transposed conv) layer on device-resident random data
  * with HIP events; used by tools/conv_bench.py to iterate on the MFMA kernels. */

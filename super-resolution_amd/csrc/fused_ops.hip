@@ -10,6 +10,7 @@
 //   teco_epilogue tanh(SRNet + bilinear x4 (LR_t)) (TecoGAN.py:74-76)
 // Activations are [B,H,W,C] with C a multiple of 16, float or bf16 (template T).
 #include "kernels.h"
+#include "gather_math.h"
 
 namespace sr {
 
@@ -33,13 +34,6 @@ template <> struct Vec<__bf16> {
 };
 
 static inline int blocks_for(long n, int bs) { return (int)((n + bs - 1) / bs); }
-
-// legacy TF1 bilinear: top = tl + (tr-tl)*tx ; bot likewise ; out = top + (bot-top)*ty
-__device__ __forceinline__ float lerp2(float tl, float tr, float bl, float br, float tx, float ty) {
-    const float top = tl + (tr - tl) * tx;
-    const float bot = bl + (br - bl) * tx;
-    return top + (bot - top) * ty;
-}
 
 // ------------------------------------------------------------------ fnet_input
 template <typename T>
@@ -173,25 +167,6 @@ hipError_t launch_resize2x(const void* in, void* out, int act_bf16, int B, int H
 }
 
 // ------------------------------------------------------------------ dense_image_warp helpers
-struct WarpCoord {
-    int f;
-    float a;
-};
-// floor clamped to [0, n-2]; alpha from the CLAMPED floor, clamped to [0,1]  
-__device__ __forceinline__ WarpCoord warp_coord(float q, int n) {
-    float f = floorf(q);
-    f = fminf(fmaxf(f, 0.f), (float)(n - 2));
-    WarpCoord w;
-    w.f = (int)f;
-    w.a = fminf(fmaxf(q - f, 0.f), 1.f);
-    return w;
-}
-__device__ __forceinline__ float warp_interp(float tl, float tr, float bl, float br, float ax, float ay) {
-    const float top = ax * (tr - tl) + tl;
-    const float bot = ax * (br - bl) + bl;
-    return ay * (bot - top) + top;
-}
-
 // ------------------------------------------------------------------ pre_srnet (the fused hot-path gather)
 // One workgroup = 64 consecutive LR pixels x 4 sub-rows (dy).  Thread (lp, dy) upsamples the
 // flow for its 4 HR pixels, gathers/warps 4 x 3 values of the previous estimate and drops them

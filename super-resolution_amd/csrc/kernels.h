@@ -81,4 +81,34 @@ hipError_t launch_resize_generic(const float* in, float* out, int B, int H, int 
 hipError_t launch_warp_generic(const float* img, const float* flow, float* out, int B, int H, int W, int C, hipStream_t s);
 hipError_t launch_s2d_generic(const float* in, float* out, int B, int H, int W, int C, int bs, hipStream_t s);
 
+// ---- training step (train_kernels.hip): fp32 NHWC tensors with explicit channel strides ----
+struct WgradArgs {
+    const float* x;    // layer input [B,H,W,xcs]
+    const float* dy;   // gradient of the layer output [B,H,W,ycs] (conv) or [B,2H,2W,ycs] (transposed conv)
+    float* part;       // workspace of wgrad_workspace_bytes()
+    float* dw;         // kernel gradient, Keras layout: conv (3,3,cin,cout), transposed conv (3,3,cout,cin)
+    float* db;         // bias gradient [cout], or nullptr
+    int B, H, W;       // input spatial dims
+    int cin, cout, xcs, ycs, convt;
+};
+size_t wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int convt);
+hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);
+// data gradient of Conv2DTranspose 3x3 s2: dy [B,2H,2W,ycs] (cout channels, a multiple of 64), w (3,3,cout,cin), dx [B,H,W,xcs]
+hipError_t launch_dgrad_s2(const float* dy, const float* w, float* dx, int B, int H, int W, int cin, int cout,
+                           int ycs, int xcs, hipStream_t s);
+hipError_t launch_act_bwd(float* g, const float* y, int act, long npix, int C, int gcs, int ycs, hipStream_t s);
+hipError_t launch_maxpool2_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, hipStream_t s);
+hipError_t launch_resize_bwd(const float* gy, float* gx, int B, int H, int W, int C, int sc, int ocs, int accumulate, hipStream_t s);
+hipError_t launch_warp_bwd_flow(const float* img, const float* flow, const float* g, float* gflow, int B, int H, int W,
+                                int C, int gfs, int accumulate, hipStream_t s);
+hipError_t launch_hr_warp_bwd(const float* est_prev, const float* flow, const float* g_sin, float* g_fhr, int B, int H, int W,
+                              int gcs, hipStream_t s);
+size_t mse_workspace_bytes(long npix, int gcs);
+hipError_t launch_mse_grad(const float* pred, const float* target, float* g, double* partial, float* loss_out, long npix, int C,
+                           int gcs, int clip01_mask, hipStream_t s);
+hipError_t launch_adam(float* p, float* m, float* v, const float* g, long n, float lr_t, float b1, float b2, float eps,
+                       float gscale, hipStream_t s);
+// ents: srh::PackEnt {int32 src, uint32 dst}[n]
+hipError_t launch_repack(const float* kernel, const void* ents, int n, void* out, int prec, hipStream_t s);
+
 }  // namespace sr

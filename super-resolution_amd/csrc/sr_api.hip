@@ -2,103 +2,33 @@
 // Owns device memory, packs Keras-layout weights into MFMA fragment order and
 // runs the generator step of reference FRVSR.py:58-66 / TecoGAN.py:68-79 as a
 // fixed sequence of HIP kernel launches on one stream.  No CPU fallback.
-#include "../../include/sr_hip.h"
-#include "kernels.h"
+#include "sr_internal.h"
 
 #include <cmath>
-#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
-#include <cstring>
 #include <functional>
-#include <map>
-#include <string>
-#include <vector>
 
 using namespace sr;
 
-namespace {
+namespace srh {
 
 thread_local std::string g_err;
 int g_conv_dbg = 0;   // ablation switches, set only by sr_bench_conv
 unsigned long long* g_conv_stamps = nullptr;
 
-struct HostTensor {
-    std::string name;
-    std::vector<int64_t> shape;
-    std::vector<float> data;
-};
-
-struct ConvLayer {
-    int mode = M_CONV;
-    int cin = 0, cout = 0, cin_p = 0;
-    int nt = 1, ncb = 1, steps = 1, nchunk = 1, wstride_cb = 0;
-    bool tapsn = false;   // <= 3 output channels: taps folded into N (conv_tapsn.hip)
-    void* d_w = nullptr;
-    float* d_bias = nullptr;
-    void* d_proj = nullptr;   // transposed conv fused with the following <= 3-channel conv: its tap-projection weights
-    double wbytes = 0;
-};
-
-struct ProfEntry {
-    std::string name;
-    double ms = 0, flops = 0, bytes = 0;
-    int64_t launches = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-};
-
-inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-
-uint16_t f2bf(float f) {   // round to nearest even
+static uint16_t f2bf(float f) {   // round to nearest even
     uint32_t u;
     memcpy(&u, &f, 4);
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
-float bf2f(uint16_t b) {
+static float bf2f(uint16_t b) {
     uint32_t u = (uint32_t)b << 16;
     float f;
     memcpy(&f, &u, 4);
     return f;
 }
-
-}  // namespace
-
-struct sr_ctx {
-    int device = 0, h = 0, w = 0, max_batch = 0, prec = P_FP32, model = SR_FRVSR;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    std::string err;
-    // weights
-    std::vector<HostTensor> tensors;      // file order
-    int n_fnet = 0, n_srnet = 0;
-    bool committed = false;
-    ConvLayer fnet[14], srnet[24];
-    // activations
-    std::map<std::string, void*> buf;
-    float *d_lr_t = nullptr, *d_lr_tm1 = nullptr, *d_est[2] = {nullptr, nullptr}, *d_flow = nullptr;
-    float *d_lr_warp = nullptr, *d_hr_warp = nullptr, *d_ss = nullptr;
-    // recurrent state
-    bool clip_active = false;
-    int clip_B = 0, cur = 0;
-    int trunk_sub = 0;   // clips per trunk sub-batch (0 = whole batch)
-    int planar_trunk = 1;   // SRNet trunk activations (sx, sy) in 64-byte planes; SR_NO_PLANAR=1 disables
-    // two lanes: a step's batch is split into halves that run on `stream` and on `stream2` between a
-    // fork and a join event, so one half's kernels fill the partial last round of workgroups (and the
-    // under-filled low-resolution FNet launches) of the other.  SR_NO_DUAL=1 disables.
-    int dual = 1;                        // number of extra lanes (0 = single stream); SR_LANES=n sets n-1
-    hipStream_t stream2[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-    hipStream_t lane_stream = nullptr;   // stream of the lane being enqueued (nullptr: `stream`)
-    int lane_b0 = 0;                     // first image of that lane
-    std::map<std::string, size_t> buf_img_bytes;   // bytes per image of every named activation buffer
-    // profiling
-    bool prof_on = false;
-    std::vector<ProfEntry> prof;
-    std::vector<hipEvent_t> ev_pool;
-};
-
-namespace {
 
 int fail(sr_ctx* c, int code, const char* fmt, ...) {
     char tmp[512];
@@ -111,12 +41,6 @@ int fail(sr_ctx* c, int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIPCHK(c, call)                                                                          \
-    do {                                                                                         \
-        hipError_t e_ = (call);                                                                  \
-        if (e_ != hipSuccess) return fail(c, SR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
-    } while (0)
-
 // ---------------------------------------------------------------- weight packing
 // Order inside one output-channel block: [pass][chunk][tap of pass][step][n block][hi,lo][lane] x 16 B
 // (conv: one pass of 9 taps; transposed conv: the four output phases of conv_mfma.hip's pass_tap),
@@ -124,8 +48,8 @@ int fail(sr_ctx* c, int code, const char* fmt, ...) {
 //   chunk*CKC + step*KS + (KS/2)*hh + e   (e < KS/2)   of output channel cb*NT*32 + n*32 + j,
 // i.e. exactly the B fragment of v_mfma_f32_32x32x2_f32 (4 successive k-pairs per vector)
 // or v_mfma_f32_32x32x16_bf16 that conv3x3_kernel consumes, in the order it consumes them.
-int pass_ntaps_h(int mode, int pass) { return mode == M_CONV ? 9 : (pass == 0 ? 4 : (pass == 3 ? 1 : 2)); }
-int pass_tap_h(int mode, int pass, int t) {
+static int pass_ntaps_h(int mode, int pass) { return mode == M_CONV ? 9 : (pass == 0 ? 4 : (pass == 3 ? 1 : 2)); }
+static int pass_tap_h(int mode, int pass, int t) {
     static const int T[4][4] = {{0, 2, 6, 8}, {1, 7, 0, 0}, {3, 5, 0, 0}, {4, 0, 0, 0}};
     return mode == M_CONV ? t : T[pass][t];
 }
@@ -158,12 +82,22 @@ void plan_layer(ConvLayer& L, int prec, int mode, int cin, int cout) {
     L.wstride_cb = L.nchunk * 9 * L.steps * L.nt * bv * 64;
 }
 
-std::vector<uint8_t> pack_weights(const ConvLayer& L, int prec, const float* w) {
+// The non-zero elements of L's packed weight buffer (see PackEnt).  kind PK_DGRAD: L is the data-gradient
+// conv of a forward Conv2D (cin, cout swapped, taps mirrored) and src indexes the FORWARD layer's kernel:
+//   dX[y,x,ci] = sum dY[y+1-ky, x+1-kx, co] W[ky,kx,ci,co]  =  conv3x3(dY, W'),  W'[ky,kx,co,ci] = W[2-ky,2-kx,ci,co]
+std::vector<PackEnt> pack_entries(const ConvLayer& L, int prec, int kind) {
     const int ks = prec_ks(prec), half = ks / 2;
     const int bv = prec == P_BF16X3 ? 2 : 1;
     const int ckc = L.steps * ks;
     const int npass = L.mode == M_CONV ? 1 : 4;
-    std::vector<uint8_t> out((size_t)L.ncb * L.wstride_cb * 16, 0);
+    std::vector<PackEnt> out;
+    // source index of the kernel element that multiplies input channel ci into output channel co at tap
+    auto W = [&](int tap, int ci, int co) -> int32_t {
+        if (ci >= L.cin || co >= L.cout) return -1;
+        if (kind == PK_DGRAD) return (int32_t)(((size_t)(8 - tap) * L.cout + co) * L.cin + ci);   // forward layer: cin_f = L.cout, cout_f = L.cin
+        if (L.mode == M_CONV) return (int32_t)(((size_t)tap * L.cin + ci) * L.cout + co);
+        return (int32_t)(((size_t)tap * L.cout + co) * L.cin + ci);   // Conv2DTranspose: (kh,kw,out,in)
+    };
     if (L.tapsn) {
         // [chunk][step][hi,lo][lane] x 16 B; lane (j, hh): GEMM column j = tap*3 + co (< 27), input
         // channels chunk*CK + step*KS + (KS/2)*hh + e  -- the A fragment conv3x3_tapsn_kernel keeps in registers
@@ -176,27 +110,12 @@ std::vector<uint8_t> pack_weights(const ConvLayer& L, int prec, const float* w) 
                     const size_t vbase = (size_t)(c * L.steps + s) * bv * 64;
                     for (int e = 0; e < half; ++e) {
                         const int ci = c * ck + s * ks + half * hh + e;
-                        float v = 0.f;
-                        if (j < 27 && co < L.cout && ci < L.cin) v = w[((size_t)tap * L.cin + ci) * L.cout + co];
-                        if (prec == P_FP32) {
-                            memcpy(&out[(vbase + lane) * 16 + e * 4], &v, 4);
-                        } else {
-                            const uint16_t hi = f2bf(v);
-                            memcpy(&out[(vbase + lane) * 16 + e * 2], &hi, 2);
-                            if (prec == P_BF16X3) {
-                                const uint16_t lo = f2bf(v - bf2f(hi));
-                                memcpy(&out[(vbase + 64 + lane) * 16 + e * 2], &lo, 2);
-                            }
-                        }
+                        const int32_t src = j < 27 ? W(tap, ci, co) : -1;
+                        if (src >= 0) out.push_back({src, (uint32_t)((vbase + lane) * half + e)});
                     }
                 }
         return out;
     }
-    auto W = [&](int ky, int kx, int ci, int co) -> float {
-        if (ci >= L.cin || co >= L.cout) return 0.f;
-        if (L.mode == M_CONV) return w[((size_t)(ky * 3 + kx) * L.cin + ci) * L.cout + co];
-        return w[((size_t)(ky * 3 + kx) * L.cout + co) * L.cin + ci];   // Conv2DTranspose: (kh,kw,out,in)
-    };
     for (int cb = 0; cb < L.ncb; ++cb) {
         size_t gstep = 0;   // k-step counter in kernel consumption order
         for (int pass = 0; pass < npass; ++pass)
@@ -211,17 +130,8 @@ std::vector<uint8_t> pack_weights(const ConvLayer& L, int prec, const float* w) 
                                 const size_t vbase = (size_t)cb * L.wstride_cb + (gstep * L.nt + n) * bv * 64;
                                 for (int e = 0; e < half; ++e) {
                                     const int ci = c * ckc + s * ks + half * hh + e;
-                                    const float v = W(tap / 3, tap % 3, ci, co);
-                                    if (prec == P_FP32) {
-                                        memcpy(&out[(vbase + lane) * 16 + e * 4], &v, 4);
-                                    } else {
-                                        const uint16_t hi = f2bf(v);
-                                        memcpy(&out[(vbase + lane) * 16 + e * 2], &hi, 2);
-                                        if (prec == P_BF16X3) {
-                                            const uint16_t lo = f2bf(v - bf2f(hi));
-                                            memcpy(&out[(vbase + 64 + lane) * 16 + e * 2], &lo, 2);
-                                        }
-                                    }
+                                    const int32_t src = W(tap, ci, co);
+                                    if (src >= 0) out.push_back({src, (uint32_t)((vbase + lane) * half + e)});
                                 }
                             }
                     }
@@ -229,10 +139,31 @@ std::vector<uint8_t> pack_weights(const ConvLayer& L, int prec, const float* w) 
     return out;
 }
 
-int upload_layer(sr_ctx* c, ConvLayer& L, int prec, const float* w, const float* bias) {
-    std::vector<uint8_t> packed = pack_weights(L, prec, w);
+// host side of the packing: zero buffer + the listed elements in the arithmetic's storage type
+static std::vector<uint8_t> pack_apply(const std::vector<PackEnt>& ents, size_t bytes, int prec, const float* w) {
+    std::vector<uint8_t> out(bytes, 0);
+    for (const PackEnt& p : ents) {
+        const float v = w[p.src];
+        if (prec == P_FP32) {
+            memcpy(&out[(size_t)p.dst * 4], &v, 4);
+        } else {
+            const uint16_t hi = f2bf(v);
+            memcpy(&out[(size_t)p.dst * 2], &hi, 2);
+            if (prec == P_BF16X3) {
+                const uint16_t lo = f2bf(v - bf2f(hi));
+                memcpy(&out[((size_t)p.dst + 512) * 2], &lo, 2);
+            }
+        }
+    }
+    return out;
+}
+
+int upload_layer(sr_ctx* c, ConvLayer& L, int prec, const float* w, const float* bias, int kind) {
+    L.ents = pack_entries(L, prec, kind);
+    std::vector<uint8_t> packed = pack_apply(L.ents, (size_t)L.ncb * L.wstride_cb * 16, prec, w);
     std::vector<float> b((size_t)L.ncb * L.nt * 32, 0.f);
-    for (int i = 0; i < L.cout; ++i) b[i] = bias[i];
+    if (bias)
+        for (int i = 0; i < L.cout; ++i) b[i] = bias[i];
     if (L.d_w) (void)hipFree(L.d_w);
     if (L.d_bias) (void)hipFree(L.d_bias);
     L.d_w = nullptr;
@@ -246,12 +177,14 @@ int upload_layer(sr_ctx* c, ConvLayer& L, int prec, const float* w, const float*
 }
 
 void free_layer(ConvLayer& L) {
-    if (L.d_w) (void)hipFree(L.d_w);
-    if (L.d_bias) (void)hipFree(L.d_bias);
-    if (L.d_proj) (void)hipFree(L.d_proj);
+    void* ps[] = {L.d_w, L.d_bias, L.d_proj, L.d_ents, L.d_proj_ents};
+    for (void* p : ps)
+        if (p) (void)hipFree(p);
     L.d_w = nullptr;
     L.d_bias = nullptr;
     L.d_proj = nullptr;
+    L.d_ents = nullptr;
+    L.d_proj_ents = nullptr;
 }
 
 // Tap-projection weights for conv_mfma.hip epilogue_proj: the following conv's kernel w[3,3,64,cout<=3]
@@ -259,29 +192,31 @@ void free_layer(ConvLayer& L) {
 // the accumulator layout of the transposed conv: k-step (n, s), lane (nn, hh), element e holds channel
 //   n*32 + 16*s + 8*(e>>2) + 4*hh + (e&3).
 // [k-step][hi,lo][lane] x 16 B for bf16x3, [k-step][lane] for bf16, [k-step][e>>2][lane] for fp32.
-int upload_proj(sr_ctx* c, ConvLayer& L, int prec, const float* w, int cout) {
+size_t proj_bytes(int prec) { return (size_t)4 * (prec == P_BF16 ? 1 : 2) * 64 * 16; }
+
+std::vector<PackEnt> proj_entries(int prec, int cout) {
     const int vps = prec == P_BF16 ? 1 : 2;
-    std::vector<uint8_t> out((size_t)4 * vps * 64 * 16, 0);
+    std::vector<PackEnt> out;
     for (int n = 0; n < 2; ++n)
         for (int s = 0; s < 2; ++s)
             for (int lane = 0; lane < 64; ++lane) {
                 const int nn = lane & 31, hh = lane >> 5, tap = nn / 3, co = nn % 3;
                 const size_t vbase = (size_t)(n * 2 + s) * vps * 64;
+                if (nn >= 27 || co >= cout) continue;
                 for (int e = 0; e < 8; ++e) {
                     const int ch = n * 32 + 16 * s + 8 * (e >> 2) + 4 * hh + (e & 3);
-                    const float v = (nn < 27 && co < cout) ? w[((size_t)tap * 64 + ch) * cout + co] : 0.f;
-                    if (prec == P_FP32) {
-                        memcpy(&out[(vbase + (e >> 2) * 64 + lane) * 16 + (e & 3) * 4], &v, 4);
-                    } else {
-                        const uint16_t hi = f2bf(v);
-                        memcpy(&out[(vbase + lane) * 16 + e * 2], &hi, 2);
-                        if (prec == P_BF16X3) {
-                            const uint16_t lo = f2bf(v - bf2f(hi));
-                            memcpy(&out[(vbase + 64 + lane) * 16 + e * 2], &lo, 2);
-                        }
-                    }
+                    const int32_t src = (int32_t)(((size_t)tap * 64 + ch) * cout + co);
+                    const uint32_t dst = prec == P_FP32 ? (uint32_t)((vbase + (e >> 2) * 64 + lane) * 4 + (e & 3))
+                                                        : (uint32_t)((vbase + lane) * 8 + e);
+                    out.push_back({src, dst});
                 }
             }
+    return out;
+}
+
+int upload_proj(sr_ctx* c, ConvLayer& L, int prec, const float* w, int cout) {
+    L.proj_ents = proj_entries(prec, cout);
+    std::vector<uint8_t> out = pack_apply(L.proj_ents, proj_bytes(prec), prec, w);
     if (L.d_proj) (void)hipFree(L.d_proj);
     L.d_proj = nullptr;
     HIPCHK(c, hipMalloc(&L.d_proj, out.size()));
@@ -309,28 +244,6 @@ hipEvent_t get_event(sr_ctx* c) {
     return e;
 }
 
-struct ProfScope {
-    sr_ctx* c;
-    size_t idx = 0;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    ProfScope(sr_ctx* c_, const char* name, double flops, double bytes) : c(c_) {
-        if (!c->prof_on) return;
-        ProfEntry* p = prof_entry(c, name);
-        idx = p - c->prof.data();
-        p->flops = flops;
-        p->bytes = bytes;
-        p->launches++;
-        e0 = get_event(c);
-        e1 = get_event(c);
-        (void)hipEventRecord(e0, c->lane_stream ? c->lane_stream : c->stream);
-    }
-    ~ProfScope() {
-        if (!e0) return;
-        (void)hipEventRecord(e1, c->lane_stream ? c->lane_stream : c->stream);
-        c->prof[idx].pending.emplace_back(e0, e1);
-    }
-};
-
 void prof_resolve(sr_ctx* c) {
     for (auto& p : c->prof) {
         for (auto& ev : p.pending) {
@@ -346,17 +259,6 @@ void prof_resolve(sr_ctx* c) {
 }
 
 // ---------------------------------------------------------------- layer launch
-struct ConvIO {
-    const void* in;
-    int H, W;              // input spatial size
-    void* out;
-    int out_cs, cout_store, out_f32;
-    const void* res;
-    int res_cs;
-    int act;
-    int in_planar = 0, out_planar = 0;   // kernels.h: planes of 64 B per pixel
-    const void* proj_w = nullptr;        // transposed conv: fused tap projection, out = P [B,2H,2W,32] fp32
-};
 
 int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, const ConvIO& io, const char* name) {
     ConvArgs a;
@@ -412,11 +314,6 @@ int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, con
     return SR_OK;
 }
 
-#define LAUNCHCHK(c, name, call)                                                               \
-    do {                                                                                       \
-        hipError_t e_ = (call);                                                                \
-        if (e_ != hipSuccess) return fail(c, SR_ERR_HIP, "launch %s: %s", name, hipGetErrorString(e_)); \
-    } while (0)
 
 int alloc_buf(sr_ctx* c, const char* name, size_t bytes) {
     void* p = nullptr;
@@ -433,8 +330,8 @@ void* lane_buf(sr_ctx* c, const char* name) {
 }
 
 // expected (cin, cout, mode) of every weighted layer, reference layers.py:30-44,67-75
-const int FNET_SPEC[14][2] = {{6, 32}, {32, 32}, {32, 64}, {64, 64}, {64, 128}, {128, 128}, {128, 256},
-                              {256, 256}, {256, 128}, {128, 128}, {128, 64}, {64, 64}, {64, 32}, {32, 2}};
+extern const int FNET_SPEC[14][2] = {{6, 32}, {32, 32}, {32, 64}, {64, 64}, {64, 128}, {128, 128}, {128, 256},
+                                     {256, 256}, {256, 128}, {128, 128}, {128, 64}, {64, 64}, {64, 32}, {32, 2}};
 
 void srnet_spec(int i, int& cin, int& cout, int& mode) {
     mode = (i == 21 || i == 22) ? M_CONVT : M_CONV;
@@ -639,7 +536,9 @@ int run_step(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, const
     return SR_OK;
 }
 
-}  // namespace
+}  // namespace srh
+
+using namespace srh;
 
 // =============================================================== C ABI
 extern "C" {
@@ -728,6 +627,7 @@ int sr_destroy(sr_ctx* c) {
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     prof_resolve(c);
+    train_free(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto& kv : c->buf) (void)hipFree(kv.second);
     float* fl[] = {c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_flow, c->d_lr_warp, c->d_hr_warp, c->d_ss};
@@ -821,12 +721,13 @@ int sr_commit_weights(sr_ctx* c) {
         if (rc) return rc;
     }
     c->committed = true;
-    return SR_OK;
+    return train_reload(c);
 }
 
 int sr_get_tensor(const sr_ctx* c, int index, char* name_out, int name_cap, float* host_out, int64_t* shape_out, int* rank_out) {
     if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
     if (index < 0 || index >= (int)c->tensors.size()) return fail(nullptr, SR_ERR_ARG, "tensor index %d out of range", index);
+    if (int rc = train_sync_host(const_cast<sr_ctx*>(c))) return rc;   // weights updated by sr_train_apply live on the device
     const HostTensor& t = c->tensors[index];
     if (name_out && name_cap > 0) snprintf(name_out, name_cap, "%s", t.name.c_str());
     if (rank_out) *rank_out = (int)t.shape.size();

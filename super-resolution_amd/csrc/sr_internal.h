@@ -1,0 +1,169 @@
+// Host-side internals shared by sr_api.hip (inference step, C ABI) and sr_train.hip (training step).
+#pragma once
+#include "../../include/sr_hip.h"
+#include "kernels.h"
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+struct sr_train_state;   // sr_train.hip
+
+namespace srh {
+
+struct HostTensor {
+    std::string name;
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+// One element of a packed weight buffer that is not a padding zero: packed[dst] = kernel[src], where
+// src indexes the layer's Keras-layout kernel and dst counts elements (float, or bf16 with the low
+// half of a bf16x3 split 512 elements = 64 vectors further on).  The same list drives the host packer
+// (sr_commit_weights) and the device re-pack after an optimizer step (sr_train.hip).
+struct PackEnt {
+    int32_t src;
+    uint32_t dst;
+};
+
+enum PackKind { PK_FWD = 0, PK_DGRAD = 1 };
+
+struct ConvLayer {
+    int mode = sr::M_CONV;
+    int cin = 0, cout = 0, cin_p = 0;
+    int nt = 1, ncb = 1, steps = 1, nchunk = 1, wstride_cb = 0;
+    bool tapsn = false;   // <= 3 output channels: taps folded into N (conv_tapsn.hip)
+    void* d_w = nullptr;
+    float* d_bias = nullptr;
+    void* d_proj = nullptr;   // transposed conv fused with the following <= 3-channel conv: its tap-projection weights
+    double wbytes = 0;
+    // packing lists (kept for the device re-pack)
+    std::vector<PackEnt> ents, proj_ents;
+    PackEnt *d_ents = nullptr, *d_proj_ents = nullptr;
+};
+
+struct ProfEntry {
+    std::string name;
+    double ms = 0, flops = 0, bytes = 0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace srh
+
+struct sr_ctx {
+    int device = 0, h = 0, w = 0, max_batch = 0, prec = sr::P_FP32, model = SR_FRVSR;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // weights
+    std::vector<srh::HostTensor> tensors;      // file order
+    int n_fnet = 0, n_srnet = 0;
+    bool committed = false;
+    srh::ConvLayer fnet[14], srnet[24];
+    // activations
+    std::map<std::string, void*> buf;
+    float *d_lr_t = nullptr, *d_lr_tm1 = nullptr, *d_est[2] = {nullptr, nullptr}, *d_flow = nullptr;
+    float *d_lr_warp = nullptr, *d_hr_warp = nullptr, *d_ss = nullptr;
+    // recurrent state
+    bool clip_active = false;
+    int clip_B = 0, cur = 0;
+    int trunk_sub = 0;   // clips per trunk sub-batch (0 = whole batch)
+    int planar_trunk = 1;   // SRNet trunk activations (sx, sy) in 64-byte planes; SR_NO_PLANAR=1 disables
+    // two lanes: a step's batch is split into halves that run on `stream` and on `stream2` between a
+    // fork and a join event, so one half's kernels fill the partial last round of workgroups (and the
+    // under-filled low-resolution FNet launches) of the other.  SR_NO_DUAL=1 disables.
+    int dual = 1;                        // number of extra lanes (0 = single stream); SR_LANES=n sets n-1
+    hipStream_t stream2[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    hipStream_t lane_stream = nullptr;   // stream of the lane being enqueued (nullptr: `stream`)
+    int lane_b0 = 0;                     // first image of that lane
+    std::map<std::string, size_t> buf_img_bytes;   // bytes per image of every named activation buffer
+    // profiling
+    bool prof_on = false;
+    std::vector<srh::ProfEntry> prof;
+    std::vector<hipEvent_t> ev_pool;
+    // training (sr_train.hip); the host copies in `tensors` are stale while train->host_stale
+    sr_train_state* train = nullptr;
+};
+
+namespace srh {
+
+int fail(sr_ctx* c, int code, const char* fmt, ...);
+
+#define HIPCHK(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return srh::fail(c, SR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+#define LAUNCHCHK(c, name, call)                                                               \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) return srh::fail(c, SR_ERR_HIP, "launch %s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+// weights
+void plan_layer(ConvLayer& L, int prec, int mode, int cin, int cout);
+std::vector<PackEnt> pack_entries(const ConvLayer& L, int prec, int kind);
+std::vector<PackEnt> proj_entries(int prec, int cout);
+size_t proj_bytes(int prec);
+int upload_layer(sr_ctx* c, ConvLayer& L, int prec, const float* w, const float* bias, int kind = PK_FWD);
+int upload_proj(sr_ctx* c, ConvLayer& L, int prec, const float* w, int cout);
+void free_layer(ConvLayer& L);
+extern const int FNET_SPEC[14][2];
+void srnet_spec(int i, int& cin, int& cout, int& mode);
+
+// profiling
+ProfEntry* prof_entry(sr_ctx* c, const char* name);
+hipEvent_t get_event(sr_ctx* c);
+
+struct ProfScope {
+    sr_ctx* c;
+    size_t idx = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(sr_ctx* c_, const char* name, double flops, double bytes) : c(c_) {
+        if (!c || !c->prof_on) return;
+        ProfEntry* p = prof_entry(c, name);
+        idx = p - c->prof.data();
+        p->flops = flops;
+        p->bytes = bytes;
+        p->launches++;
+        e0 = get_event(c);
+        e1 = get_event(c);
+        (void)hipEventRecord(e0, c->lane_stream ? c->lane_stream : c->stream);
+    }
+    ~ProfScope() {
+        if (!e0) return;
+        (void)hipEventRecord(e1, c->lane_stream ? c->lane_stream : c->stream);
+        c->prof[idx].pending.emplace_back(e0, e1);
+    }
+};
+
+// layer launch
+struct ConvIO {
+    const void* in;
+    int H, W;              // input spatial size
+    void* out;
+    int out_cs, cout_store, out_f32;
+    const void* res;
+    int res_cs;
+    int act;
+    int in_planar = 0, out_planar = 0;   // kernels.h: planes of 64 B per pixel
+    const void* proj_w = nullptr;        // transposed conv: fused tap projection, out = P [B,2H,2W,32] fp32
+};
+
+int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, const ConvIO& io, const char* name);
+int check_ready(sr_ctx* c, int B);
+
+// sr_train.hip
+void train_free(sr_ctx* c);
+int train_sync_host(sr_ctx* c);   // refresh ctx->tensors from the device master weights after training
+int train_reload(sr_ctx* c);      // after sr_commit_weights: master weights and packed buffers follow the host tensors
+
+}  // namespace srh

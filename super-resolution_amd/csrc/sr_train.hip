@@ -1,0 +1,652 @@
+// Training step of the FRVSR generator on the device: replaces frvsr.train_on_batch (reference
+// FRVSR.py:156) for the model compiled at FRVSR.py:69-71 (two mean-squared-error losses with weights
+// 1, 1 and Adam(lr=1e-4)).  Forward with every activation kept, backward in reverse graph order,
+// gradients into one flat fp32 vector in the Keras file order (the buffer a data-parallel job
+// all-reduces), Adam on the flat master weights, device re-pack of the MFMA weight buffers.
+//
+//   forward / data gradients of the stride-1 convs: the inference MFMA kernels (conv_mfma.hip,
+//   conv_tapsn.hip); the data gradient is the same convolution with mirrored, transposed weights
+//   weight gradients, transposed-conv data gradient, gathers: train_kernels.hip
+#include "sr_internal.h"
+
+#include <cmath>
+#include <cstdio>
+
+using namespace sr;
+using namespace srh;
+
+struct sr_train_state {
+    int64_t nparams = 0;
+    int64_t off[77] = {0};              // offsets of the 76 tensors in the flat vectors
+    float *d_params = nullptr, *d_m = nullptr, *d_v = nullptr, *d_grad = nullptr;
+    int64_t t = 0;                      // optimizer iterations
+    bool host_stale = false;            // ctx->tensors older than d_params
+    ConvLayer fnet_dg[14], srnet_dg[24];   // data-gradient convs of the Conv2D layers (planned where needed)
+    std::map<std::string, float*> act;  // saved activations and gradient work buffers
+    float* part = nullptr;              // wgrad partial sums
+    double* mse_part = nullptr;
+    float* d_loss = nullptr;            // [sr, flow]
+};
+
+namespace {
+
+void layer_dims(bool is_f, int i, int& cin, int& cout, int& mode) {
+    if (is_f) {
+        cin = FNET_SPEC[i][0];
+        cout = FNET_SPEC[i][1];
+        mode = M_CONV;
+    } else {
+        srnet_spec(i, cin, cout, mode);
+    }
+}
+
+int talloc(sr_ctx* c, const char* name, size_t floats) {
+    float* p = nullptr;
+    HIPCHK(c, hipMalloc((void**)&p, floats * sizeof(float)));
+    c->train->act[name] = p;
+    return SR_OK;
+}
+
+int upload_ents(sr_ctx* c, const std::vector<PackEnt>& ents, PackEnt** d) {
+    if (*d || ents.empty()) return SR_OK;
+    HIPCHK(c, hipMalloc((void**)d, ents.size() * sizeof(PackEnt)));
+    HIPCHK(c, hipMemcpy(*d, ents.data(), ents.size() * sizeof(PackEnt), hipMemcpyHostToDevice));
+    return SR_OK;
+}
+
+int upload_params(sr_ctx* c) {
+    sr_train_state* T = c->train;
+    for (int i = 0; i < 76; ++i)
+        HIPCHK(c, hipMemcpy(T->d_params + T->off[i], c->tensors[i].data.data(), c->tensors[i].data.size() * 4, hipMemcpyHostToDevice));
+    T->host_stale = false;
+    return SR_OK;
+}
+
+// first training call: master weights, optimizer state, dgrad layers, activation tape
+int train_init(sr_ctx* c) {
+    if (c->train) return SR_OK;
+    if (c->prec == P_BF16)
+        return fail(c, SR_ERR_ARG, "training needs fp32 activations: create the ctx with dtype fp32 or bf16x3");
+    if (c->model != SR_FRVSR)
+        return fail(c, SR_ERR_ARG, "training covers the FRVSR model (reference FRVSR.py:69-71); the TecoGAN losses are not built");
+    sr_train_state* T = new sr_train_state();
+    c->train = T;
+    for (int i = 0; i < 76; ++i) T->off[i + 1] = T->off[i] + (int64_t)c->tensors[i].data.size();
+    T->nparams = T->off[76];
+    const size_t nb = (size_t)T->nparams * 4;
+    HIPCHK(c, hipMalloc((void**)&T->d_params, nb));
+    HIPCHK(c, hipMalloc((void**)&T->d_m, nb));
+    HIPCHK(c, hipMalloc((void**)&T->d_v, nb));
+    HIPCHK(c, hipMalloc((void**)&T->d_grad, nb));
+    HIPCHK(c, hipMemset(T->d_m, 0, nb));
+    HIPCHK(c, hipMemset(T->d_v, 0, nb));
+    HIPCHK(c, hipMemset(T->d_grad, 0, nb));
+    int rc = upload_params(c);
+    if (rc) return rc;
+    // data-gradient convs (FNet's first layer has no input gradient; the transposed convs use dgrad_s2)
+    size_t part_bytes = 0;
+    const int h = c->h, w = c->w, B = c->max_batch;
+    for (int g = 0; g < 2; ++g) {
+        const bool is_f = g == 0;
+        const int nl = is_f ? 14 : 24;
+        for (int i = 0; i < nl; ++i) {
+            int cin, cout, mode;
+            layer_dims(is_f, i, cin, cout, mode);
+            ConvLayer& L = is_f ? c->fnet[i] : c->srnet[i];
+            if ((rc = upload_ents(c, L.ents, &L.d_ents))) return rc;
+            if ((rc = upload_ents(c, L.proj_ents, &L.d_proj_ents))) return rc;
+            // spatial size of the layer's input, for the wgrad workspace
+            int H = h, W = w;
+            if (is_f) {
+                const int lvl[14] = {0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 1, 1, 0, 0};
+                H = h >> lvl[i];
+                W = w >> lvl[i];
+            } else if (i == 22) {
+                H = 2 * h;
+                W = 2 * w;
+            } else if (i == 23) {
+                H = 4 * h;
+                W = 4 * w;
+            }
+            part_bytes = std::max(part_bytes, wgrad_workspace_bytes(B, H, W, cin, cout, mode == M_CONVT));
+            if (mode == M_CONVT || (is_f && i == 0)) continue;
+            ConvLayer& D = is_f ? T->fnet_dg[i] : T->srnet_dg[i];
+            plan_layer(D, c->prec, M_CONV, cout, cin);
+            const float* wk = c->tensors[(is_f ? 0 : 28) + 2 * i].data.data();
+            if ((rc = upload_layer(c, D, c->prec, wk, nullptr, PK_DGRAD))) return rc;
+            if ((rc = upload_ents(c, D.ents, &D.d_ents))) return rc;
+        }
+    }
+    HIPCHK(c, hipMalloc((void**)&T->part, part_bytes));
+    // activation tape and gradient work buffers, fp32, per image sizes in floats
+    const size_t L0 = (size_t)h * w, L1 = L0 / 4, L2 = L0 / 16, L3 = L0 / 64, Bz = B;
+    struct { const char* n; size_t elems; } plan[] = {
+        {"x0", L0 * 16}, {"e0a", L0 * 32}, {"e0b", L0 * 32}, {"p1", L1 * 32}, {"e1a", L1 * 64}, {"e1b", L1 * 64},
+        {"p2", L2 * 64}, {"e2a", L2 * 128}, {"e2b", L2 * 128}, {"p3", L3 * 128}, {"e3a", L3 * 256}, {"e3b", L3 * 256},
+        {"u2", L2 * 256}, {"d2a", L2 * 128}, {"d2b", L2 * 128}, {"u1", L1 * 128}, {"d1a", L1 * 64}, {"d1b", L1 * 64},
+        {"u0", L0 * 64}, {"c13", L0 * 32}, {"s_in", L0 * 64}, {"up1", L0 * 4 * 64}, {"up2", L0 * 16 * 64},
+        {"gA", L0 * 16 * 64}, {"gB", L0 * 16 * 64}, {"g_est", L0 * 16 * 16}, {"g_flow", L0 * 16}, {"g_fhr", L0 * 16 * 2},
+        {"g_lw", L0 * 3}, {"hr", L0 * 48}};
+    for (auto& p : plan)
+        if ((rc = talloc(c, p.n, Bz * p.elems))) return rc;
+    char nm[16];
+    for (int r = 0; r <= 10; ++r) {
+        snprintf(nm, sizeof nm, "x%d_", r);
+        if ((rc = talloc(c, nm, Bz * L0 * 64))) return rc;
+        if (r < 10) {
+            snprintf(nm, sizeof nm, "y%d_", r);
+            if ((rc = talloc(c, nm, Bz * L0 * 64))) return rc;
+        }
+    }
+    const size_t mse_bytes = std::max(mse_workspace_bytes((long)(Bz * L0 * 16), 16), mse_workspace_bytes((long)(Bz * L0), 3));
+    HIPCHK(c, hipMalloc((void**)&T->mse_part, mse_bytes));
+    HIPCHK(c, hipMalloc((void**)&T->d_loss, 2 * sizeof(float)));
+    return SR_OK;
+}
+
+struct Tape {
+    sr_ctx* c;
+    sr_train_state* T;
+    int B, P;
+    hipStream_t st;
+    float* a(const char* n) { return T->act[n]; }
+
+    int conv(const ConvLayer& L, const float* in, int H, int W, float* out, int out_cs, int cout_store, int act,
+             const float* res, const char* name) {
+        return run_conv(c, P, st, L, B, {in, H, W, out, out_cs, cout_store, 1, res, out_cs, act}, name);
+    }
+    // kernel + bias gradient of tensor pair `ti` (index of the kernel in file order)
+    int wgrad(int ti, int mode, int cin, int cout, const float* x, int xcs, const float* dy, int ycs, int H, int W) {
+        WgradArgs wa;
+        wa.x = x;
+        wa.dy = dy;
+        wa.part = T->part;
+        wa.dw = T->d_grad + T->off[ti];
+        wa.db = T->d_grad + T->off[ti + 1];
+        wa.B = B;
+        wa.H = H;
+        wa.W = W;
+        wa.cin = cin;
+        wa.cout = cout;
+        wa.xcs = xcs;
+        wa.ycs = ycs;
+        wa.convt = mode == M_CONVT;
+        const double px = (double)B * H * W;
+        ProfScope ps(c, mode == M_CONVT ? "train.wgradT" : "train.wgrad", px * 18.0 * cin * cout, px * 4.0 * (cin + (mode == M_CONVT ? 4 : 1) * cout));
+        LAUNCHCHK(c, "wgrad", launch_wgrad(wa, st));
+        return SR_OK;
+    }
+    int mask(float* g, const float* y, int act, long npix, int C, int gcs, int ycs) {
+        ProfScope ps(c, "train.act_bwd", 0, (double)npix * C * 12.0);
+        LAUNCHCHK(c, "act_bwd", launch_act_bwd(g, y, act, npix, C, gcs, ycs, st));
+        return SR_OK;
+    }
+};
+
+#define RC(call)                  \
+    do {                          \
+        int rc_ = (call);         \
+        if (rc_) return rc_;      \
+    } while (0)
+
+// forward of reference FRVSR.py:58-63 with every layer output kept (fp32 NHWC, no planar trunk, no fused tail)
+int train_forward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const float* d_est_prev, float* d_est, float* d_lr_warp,
+                  float* d_flow) {
+    sr_ctx* c = t.c;
+    const int B = t.B, H = c->h, W = c->w;
+    hipStream_t st = t.st;
+    LAUNCHCHK(c, "fnet.input", launch_fnet_input(d_lr_t, d_lr_tm1, t.a("x0"), 0, B, H, W, st));
+    const ConvLayer* F = c->fnet;
+    // encoder
+    RC(t.conv(F[0], t.a("x0"), H, W, t.a("e0a"), 32, 32, A_LRELU, nullptr, "train.fwd"));
+    RC(t.conv(F[1], t.a("e0a"), H, W, t.a("e0b"), 32, 32, A_LRELU, nullptr, "train.fwd"));
+    LAUNCHCHK(c, "pool", launch_maxpool2(t.a("e0b"), t.a("p1"), 0, B, H, W, 32, st));
+    RC(t.conv(F[2], t.a("p1"), H / 2, W / 2, t.a("e1a"), 64, 64, A_LRELU, nullptr, "train.fwd"));
+    RC(t.conv(F[3], t.a("e1a"), H / 2, W / 2, t.a("e1b"), 64, 64, A_LRELU, nullptr, "train.fwd"));
+    LAUNCHCHK(c, "pool", launch_maxpool2(t.a("e1b"), t.a("p2"), 0, B, H / 2, W / 2, 64, st));
+    RC(t.conv(F[4], t.a("p2"), H / 4, W / 4, t.a("e2a"), 128, 128, A_LRELU, nullptr, "train.fwd"));
+    RC(t.conv(F[5], t.a("e2a"), H / 4, W / 4, t.a("e2b"), 128, 128, A_LRELU, nullptr, "train.fwd"));
+    LAUNCHCHK(c, "pool", launch_maxpool2(t.a("e2b"), t.a("p3"), 0, B, H / 4, W / 4, 128, st));
+    RC(t.conv(F[6], t.a("p3"), H / 8, W / 8, t.a("e3a"), 256, 256, A_LRELU, nullptr, "train.fwd"));
+    RC(t.conv(F[7], t.a("e3a"), H / 8, W / 8, t.a("e3b"), 256, 256, A_LRELU, nullptr, "train.fwd"));
+    // decoder
+    LAUNCHCHK(c, "resize", launch_resize2x(t.a("e3b"), t.a("u2"), 0, B, H / 8, W / 8, 256, st));
+    RC(t.conv(F[8], t.a("u2"), H / 4, W / 4, t.a("d2a"), 128, 128, A_LRELU, nullptr, "train.fwd"));
+    RC(t.conv(F[9], t.a("d2a"), H / 4, W / 4, t.a("d2b"), 128, 128, A_LRELU, nullptr, "train.fwd"));
+    LAUNCHCHK(c, "resize", launch_resize2x(t.a("d2b"), t.a("u1"), 0, B, H / 4, W / 4, 128, st));
+    RC(t.conv(F[10], t.a("u1"), H / 2, W / 2, t.a("d1a"), 64, 64, A_LRELU, nullptr, "train.fwd"));
+    RC(t.conv(F[11], t.a("d1a"), H / 2, W / 2, t.a("d1b"), 64, 64, A_LRELU, nullptr, "train.fwd"));
+    LAUNCHCHK(c, "resize", launch_resize2x(t.a("d1b"), t.a("u0"), 0, B, H / 2, W / 2, 64, st));
+    RC(t.conv(F[12], t.a("u0"), H, W, t.a("c13"), 32, 32, A_LRELU, nullptr, "train.fwd"));
+    RC(t.conv(F[13], t.a("c13"), H, W, d_flow, 2, 2, A_TANH, nullptr, "train.fwd"));
+    // warps
+    LAUNCHCHK(c, "lr_warp", launch_warp3(d_lr_tm1, d_flow, d_lr_warp, B, H, W, st));
+    LAUNCHCHK(c, "pre_srnet", launch_pre_srnet(d_flow, d_est_prev, d_lr_t, t.a("s_in"), nullptr, 0, B, H, W, st));
+    // SRNet
+    const ConvLayer* S = c->srnet;
+    char xn[16], yn[16], xn1[16];
+    RC(t.conv(S[0], t.a("s_in"), H, W, t.a("x0_"), 64, 64, A_RELU, nullptr, "train.fwd"));
+    for (int r = 0; r < 10; ++r) {
+        snprintf(xn, sizeof xn, "x%d_", r);
+        snprintf(yn, sizeof yn, "y%d_", r);
+        snprintf(xn1, sizeof xn1, "x%d_", r + 1);
+        RC(t.conv(S[1 + 2 * r], t.a(xn), H, W, t.a(yn), 64, 64, A_RELU, nullptr, "train.fwd"));
+        RC(t.conv(S[2 + 2 * r], t.a(yn), H, W, t.a(xn1), 64, 64, A_NONE, t.a(xn), "train.fwd"));
+    }
+    RC(t.conv(S[21], t.a("x10_"), H, W, t.a("up1"), 64, 64, A_RELU, nullptr, "train.fwd"));
+    RC(t.conv(S[22], t.a("up1"), 2 * H, 2 * W, t.a("up2"), 64, 64, A_RELU, nullptr, "train.fwd"));
+    RC(t.conv(S[23], t.a("up2"), 4 * H, 4 * W, d_est, 3, 3, A_CLIP01, nullptr, "train.fwd"));
+    return SR_OK;
+}
+
+int train_backward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const float* d_est_prev, const float* d_hr,
+                   const float* d_est, const float* d_lr_warp, const float* d_flow) {
+    sr_ctx* c = t.c;
+    sr_train_state* T = t.T;
+    const int B = t.B, H = c->h, W = c->w;
+    hipStream_t st = t.st;
+    const long L0 = (long)B * H * W;
+    float *cur = t.a("gA"), *oth = t.a("gB");
+    auto swap = [&]() { std::swap(cur, oth); };
+    const ConvLayer* SD = T->srnet_dg;
+    const int so = 28;   // index of SRNet's first tensor
+    // ---- losses (Keras: mean over all elements) and their gradients
+    LAUNCHCHK(c, "mse", launch_mse_grad(d_est, d_hr, t.a("g_est"), T->mse_part, T->d_loss, 16 * L0, 3, 16, 1, st));
+    // ---- SRNet, reverse order (reference layers.py:66-76)
+    RC(t.wgrad(so + 46, M_CONV, 64, 3, t.a("up2"), 64, t.a("g_est"), 16, 4 * H, 4 * W));
+    RC(t.conv(SD[23], t.a("g_est"), 4 * H, 4 * W, cur, 64, 64, A_NONE, nullptr, "train.dgrad"));
+    RC(t.mask(cur, t.a("up2"), A_RELU, 16 * L0, 64, 64, 64));
+    RC(t.wgrad(so + 44, M_CONVT, 64, 64, t.a("up1"), 64, cur, 64, 2 * H, 2 * W));
+    {
+        ProfScope ps(c, "train.dgrad_s2", 4.0 * L0 * 18 * 64 * 64, 4.0 * L0 * 4 * (4 * 64 + 64));
+        LAUNCHCHK(c, "dgrad_s2", launch_dgrad_s2(cur, T->d_params + T->off[so + 44], oth, B, 2 * H, 2 * W, 64, 64, 64, 64, st));
+    }
+    swap();
+    RC(t.mask(cur, t.a("up1"), A_RELU, 4 * L0, 64, 64, 64));
+    RC(t.wgrad(so + 42, M_CONVT, 64, 64, t.a("x10_"), 64, cur, 64, H, W));
+    {
+        ProfScope ps(c, "train.dgrad_s2", 1.0 * L0 * 18 * 64 * 64, 1.0 * L0 * 4 * (4 * 64 + 64));
+        LAUNCHCHK(c, "dgrad_s2", launch_dgrad_s2(cur, T->d_params + T->off[so + 42], oth, B, H, W, 64, 64, 64, 64, st));
+    }
+    swap();   // cur = g_x
+    char xn[16], yn[16];
+    for (int r = 9; r >= 0; --r) {
+        snprintf(xn, sizeof xn, "x%d_", r);
+        snprintf(yn, sizeof yn, "y%d_", r);
+        const int l2 = 2 + 2 * r, l1 = 1 + 2 * r;
+        RC(t.wgrad(so + 2 * l2, M_CONV, 64, 64, t.a(yn), 64, cur, 64, H, W));
+        RC(t.conv(SD[l2], cur, H, W, oth, 64, 64, A_NONE, nullptr, "train.dgrad"));
+        RC(t.mask(oth, t.a(yn), A_RELU, L0, 64, 64, 64));
+        RC(t.wgrad(so + 2 * l1, M_CONV, 64, 64, t.a(xn), 64, oth, 64, H, W));
+        RC(t.conv(SD[l1], oth, H, W, cur, 64, 64, A_NONE, cur, "train.dgrad"));   // g_x += dgrad, in place like the forward
+    }
+    RC(t.mask(cur, t.a("x0_"), A_RELU, L0, 64, 64, 64));
+    RC(t.wgrad(so + 0, M_CONV, 51, 64, t.a("s_in"), 64, cur, 64, H, W));
+    RC(t.conv(SD[0], cur, H, W, oth, 64, 51, A_NONE, nullptr, "train.dgrad"));
+    swap();   // cur = gradient of SRNet's input [.., 64], channels 3..50 = space_to_depth(warped estimate)
+    // ---- warps: gradient w.r.t. the flow only (the previous estimate and LR frame are constants)
+    {
+        ProfScope ps(c, "train.warp_bwd", 0, (double)L0 * 16 * (12 + 12 + 8) + (double)L0 * 256);
+        LAUNCHCHK(c, "hr_warp_bwd", launch_hr_warp_bwd(d_est_prev, d_flow, cur, t.a("g_fhr"), B, H, W, 64, st));
+        HIPCHK(c, hipMemsetAsync(t.a("g_flow"), 0, (size_t)L0 * 16 * 4, st));
+        LAUNCHCHK(c, "resize_bwd", launch_resize_bwd(t.a("g_fhr"), t.a("g_flow"), B, H, W, 2, 4, 16, 0, st));
+        LAUNCHCHK(c, "mse", launch_mse_grad(d_lr_warp, d_lr_t, t.a("g_lw"), T->mse_part, T->d_loss + 1, L0, 3, 3, 0, st));
+        LAUNCHCHK(c, "warp_bwd_flow", launch_warp_bwd_flow(d_lr_tm1, d_flow, t.a("g_lw"), t.a("g_flow"), B, H, W, 3, 16, 1, st));
+    }
+    RC(t.mask(t.a("g_flow"), d_flow, A_TANH, L0, 2, 16, 2));
+    // ---- FNet, reverse order (reference layers.py:27-45)
+    const ConvLayer* FD = T->fnet_dg;
+    auto pool_bwd = [&](const char* x, int h, int w, int C) -> int {   // gradient of x's 2x2 pooled output in cur -> oth
+        ProfScope ps(c, "train.pool_bwd", 0, (double)B * h * w * C * 4 * 2.25);
+        LAUNCHCHK(c, "maxpool2_bwd", launch_maxpool2_bwd(t.a(x), cur, oth, B, h, w, C, st));
+        return SR_OK;
+    };
+    auto resize_bwd = [&](int h, int w, int C) -> int {   // cur [B,2h,2w,C] -> oth [B,h,w,C]
+        ProfScope ps(c, "train.resize_bwd", 0, (double)B * h * w * C * 4 * 5.0);
+        LAUNCHCHK(c, "resize_bwd", launch_resize_bwd(cur, oth, B, h, w, C, 2, C, 0, st));
+        return SR_OK;
+    };
+    // one conv layer: cur = dL/d(out) with the activation mask already applied
+    auto conv_bwd = [&](int i, const char* x, int xcs, const float* dy, int ycs, int h, int w, float* dx) -> int {
+        const int cin = FNET_SPEC[i][0], cout = FNET_SPEC[i][1];
+        RC(t.wgrad(2 * i, M_CONV, cin, cout, t.a(x), xcs, dy, ycs, h, w));
+        if (dx) RC(t.conv(FD[i], dy, h, w, dx, cin, cin, A_NONE, nullptr, "train.dgrad"));
+        return SR_OK;
+    };
+    const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8;
+    RC(conv_bwd(13, "c13", 32, t.a("g_flow"), 16, H, W, cur));
+    RC(t.mask(cur, t.a("c13"), A_LRELU, L0, 32, 32, 32));
+    RC(conv_bwd(12, "u0", 64, cur, 32, H, W, oth));
+    swap();
+    RC(resize_bwd(H1, W1, 64));
+    swap();
+    RC(t.mask(cur, t.a("d1b"), A_LRELU, L0 / 4, 64, 64, 64));
+    RC(conv_bwd(11, "d1a", 64, cur, 64, H1, W1, oth));
+    swap();
+    RC(t.mask(cur, t.a("d1a"), A_LRELU, L0 / 4, 64, 64, 64));
+    RC(conv_bwd(10, "u1", 128, cur, 64, H1, W1, oth));
+    swap();
+    RC(resize_bwd(H2, W2, 128));
+    swap();
+    RC(t.mask(cur, t.a("d2b"), A_LRELU, L0 / 16, 128, 128, 128));
+    RC(conv_bwd(9, "d2a", 128, cur, 128, H2, W2, oth));
+    swap();
+    RC(t.mask(cur, t.a("d2a"), A_LRELU, L0 / 16, 128, 128, 128));
+    RC(conv_bwd(8, "u2", 256, cur, 128, H2, W2, oth));
+    swap();
+    RC(resize_bwd(H3, W3, 256));
+    swap();
+    RC(t.mask(cur, t.a("e3b"), A_LRELU, L0 / 64, 256, 256, 256));
+    RC(conv_bwd(7, "e3a", 256, cur, 256, H3, W3, oth));
+    swap();
+    RC(t.mask(cur, t.a("e3a"), A_LRELU, L0 / 64, 256, 256, 256));
+    RC(conv_bwd(6, "p3", 128, cur, 256, H3, W3, oth));
+    swap();
+    RC(pool_bwd("e2b", H2, W2, 128));
+    swap();
+    RC(t.mask(cur, t.a("e2b"), A_LRELU, L0 / 16, 128, 128, 128));
+    RC(conv_bwd(5, "e2a", 128, cur, 128, H2, W2, oth));
+    swap();
+    RC(t.mask(cur, t.a("e2a"), A_LRELU, L0 / 16, 128, 128, 128));
+    RC(conv_bwd(4, "p2", 64, cur, 128, H2, W2, oth));
+    swap();
+    RC(pool_bwd("e1b", H1, W1, 64));
+    swap();
+    RC(t.mask(cur, t.a("e1b"), A_LRELU, L0 / 4, 64, 64, 64));
+    RC(conv_bwd(3, "e1a", 64, cur, 64, H1, W1, oth));
+    swap();
+    RC(t.mask(cur, t.a("e1a"), A_LRELU, L0 / 4, 64, 64, 64));
+    RC(conv_bwd(2, "p1", 32, cur, 64, H1, W1, oth));
+    swap();
+    RC(pool_bwd("e0b", H, W, 32));
+    swap();
+    RC(t.mask(cur, t.a("e0b"), A_LRELU, L0, 32, 32, 32));
+    RC(conv_bwd(1, "e0a", 32, cur, 32, H, W, oth));
+    swap();
+    RC(t.mask(cur, t.a("e0a"), A_LRELU, L0, 32, 32, 32));
+    RC(conv_bwd(0, "x0", 16, cur, 32, H, W, nullptr));
+    return SR_OK;
+}
+
+int grads_common(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1, const float* hr_t,
+                 float* d_grads_out, float* losses, bool dev) {
+    int rc = check_ready(c, B);
+    if (rc) return rc;
+    if (!lr_t || !lr_tm1 || !est_tm1 || !hr_t) return fail(c, SR_ERR_ARG, "NULL tensor pointer");
+    if ((rc = train_init(c))) {
+        train_free(c);   // a half-built state must not survive
+        return rc;
+    }
+    sr_train_state* T = c->train;
+    c->clip_active = false;   // borrows the state buffers
+    const size_t nlr = (size_t)B * c->h * c->w * 3 * 4, nhr = nlr * 16;
+    hipStream_t st = c->stream;
+    const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, kind, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, lr_tm1, nlr, kind, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, kind, st));
+    HIPCHK(c, hipMemcpyAsync(T->act["hr"], hr_t, nhr, kind, st));
+    Tape t{c, T, B, c->prec, st};
+    if ((rc = train_forward(t, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
+    if ((rc = train_backward(t, c->d_lr_t, c->d_lr_tm1, c->d_est[0], T->act["hr"], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
+    if (d_grads_out) HIPCHK(c, hipMemcpyAsync(d_grads_out, T->d_grad, (size_t)T->nparams * 4, hipMemcpyDeviceToDevice, st));
+    float l[2] = {0.f, 0.f};
+    HIPCHK(c, hipMemcpyAsync(l, T->d_loss, sizeof l, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (losses) {   // Keras train_on_batch order: [total, output 1, output 2] (reference FRVSR.py:161)
+        losses[0] = l[0] + l[1];
+        losses[1] = l[0];
+        losses[2] = l[1];
+    }
+    return SR_OK;
+}
+
+// packed MFMA buffers of every conv (forward, data gradient, fused tap projection) from the master weights
+int repack_all(sr_ctx* c) {
+    sr_train_state* T = c->train;
+    hipStream_t st = c->stream;
+    for (int g = 0; g < 2; ++g) {
+        const bool is_f = g == 0;
+        const int nl = is_f ? 14 : 24, base = is_f ? 0 : 28;
+        for (int i = 0; i < nl; ++i) {
+            ConvLayer& L = is_f ? c->fnet[i] : c->srnet[i];
+            const float* wk = T->d_params + T->off[base + 2 * i];
+            LAUNCHCHK(c, "repack", launch_repack(wk, L.d_ents, (int)L.ents.size(), L.d_w, c->prec, st));
+            HIPCHK(c, hipMemcpyAsync(L.d_bias, T->d_params + T->off[base + 2 * i + 1], (size_t)L.cout * 4, hipMemcpyDeviceToDevice, st));
+            ConvLayer& D = is_f ? T->fnet_dg[i] : T->srnet_dg[i];
+            if (D.d_w) LAUNCHCHK(c, "repack", launch_repack(wk, D.d_ents, (int)D.ents.size(), D.d_w, c->prec, st));
+        }
+    }
+    ConvLayer& U = c->srnet[22];
+    if (U.d_proj)
+        LAUNCHCHK(c, "repack", launch_repack(T->d_params + T->off[28 + 46], U.d_proj_ents, (int)U.proj_ents.size(), U.d_proj, c->prec, st));
+    return SR_OK;
+}
+
+}  // namespace
+
+namespace srh {
+
+void train_free(sr_ctx* c) {
+    sr_train_state* T = c->train;
+    if (!T) return;
+    float* fl[] = {T->d_params, T->d_m, T->d_v, T->d_grad, T->part, T->d_loss};
+    for (auto p : fl)
+        if (p) (void)hipFree(p);
+    if (T->mse_part) (void)hipFree(T->mse_part);
+    for (auto& kv : T->act) (void)hipFree(kv.second);
+    for (auto& L : T->fnet_dg) free_layer(L);
+    for (auto& L : T->srnet_dg) free_layer(L);
+    delete T;
+    c->train = nullptr;
+}
+
+int train_sync_host(sr_ctx* c) {
+    sr_train_state* T = c->train;
+    if (!T || !T->host_stale) return SR_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 76; ++i)
+        HIPCHK(c, hipMemcpy(c->tensors[i].data.data(), T->d_params + T->off[i], c->tensors[i].data.size() * 4, hipMemcpyDeviceToHost));
+    T->host_stale = false;
+    return SR_OK;
+}
+
+// a new load_weights (sr_commit_weights) replaces the master weights; Keras keeps the optimizer state
+int train_reload(sr_ctx* c) {
+    if (!c->train) return SR_OK;
+    int rc = upload_params(c);
+    if (rc) return rc;
+    return repack_all(c);   // the dgrad and projection buffers follow the new weights
+}
+
+}  // namespace srh
+
+extern "C" {
+
+int sr_train_param_count(const sr_ctx* c, int64_t* n) {
+    if (!c || !n) return fail(nullptr, SR_ERR_ARG, "NULL argument");
+    if (!c->committed) return fail(nullptr, SR_ERR_WEIGHTS, "weights not committed");
+    int64_t s = 0;
+    for (const auto& t : c->tensors) s += (int64_t)t.data.size();
+    *n = s;
+    return SR_OK;
+}
+
+int sr_train_grads(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1, const float* hr_t,
+                   float* d_grads, float* losses) {
+    return grads_common(c, B, lr_t, lr_tm1, est_tm1, hr_t, d_grads, losses, false);
+}
+
+int sr_train_grads_dev(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1, const float* hr_t,
+                       float* d_grads, float* losses) {
+    return grads_common(c, B, lr_t, lr_tm1, est_tm1, hr_t, d_grads, losses, true);
+}
+
+int sr_train_read_grads(sr_ctx* c, float* host_out) {
+    if (!c || !host_out) return fail(c, SR_ERR_ARG, "NULL argument");
+    if (!c->train) return fail(c, SR_ERR_STATE, "no gradients: call sr_train_grads first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(host_out, c->train->d_grad, (size_t)c->train->nparams * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+int sr_train_apply(sr_ctx* c, const float* d_grads, float grad_scale, float lr, float beta1, float beta2, float eps) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    if (!c->train) return fail(c, SR_ERR_STATE, "no gradients: call sr_train_grads first");
+    HIPCHK(c, hipSetDevice(c->device));
+    sr_train_state* T = c->train;
+    T->t += 1;
+    // Keras 2.2.4 Adam.get_updates: lr_t = lr * sqrt(1 - beta_2^t) / (1 - beta_1^t)
+    const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)T->t)) / (1.0 - std::pow((double)beta1, (double)T->t));
+    LAUNCHCHK(c, "adam", launch_adam(T->d_params, T->d_m, T->d_v, d_grads ? d_grads : T->d_grad, T->nparams, (float)lr_t, beta1,
+                                     beta2, eps, grad_scale, c->stream));
+    T->host_stale = true;
+    return repack_all(c);
+}
+
+int sr_train_on_batch(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1, const float* hr_t,
+                      float lr, float* losses) {
+    int rc = grads_common(c, B, lr_t, lr_tm1, est_tm1, hr_t, nullptr, losses, false);
+    if (rc) return rc;
+    return sr_train_apply(c, nullptr, 1.f, lr, 0.9f, 0.999f, 1e-7f);
+}
+
+int64_t sr_train_iterations(const sr_ctx* c) { return (c && c->train) ? c->train->t : 0; }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- single backward ops (parity tests)
+namespace {
+struct DevBufs {
+    std::vector<void*> p;
+    ~DevBufs() {
+        for (auto q : p) (void)hipFree(q);
+    }
+    float* get(size_t floats) {
+        void* q = nullptr;
+        if (hipMalloc(&q, (floats ? floats : 4) * 4) != hipSuccess) return nullptr;
+        p.push_back(q);
+        return (float*)q;
+    }
+    float* put(const float* host, size_t floats) {
+        float* q = get(floats);
+        if (q && hipMemcpy(q, host, floats * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return q;
+    }
+};
+
+int bwd_prologue(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, SR_ERR_HIP, "no HIP device available; libsr_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(nullptr, SR_ERR_ARG, "device %d out of range", device);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, SR_ERR_HIP, "hipSetDevice failed");
+    return SR_OK;
+}
+
+int conv_bwd_op(int device, int dtype, int convt, int B, int H, int W, int Cin, int Cout, const float* x, const float* w,
+                const float* dy, float* dx, float* dw, float* db) {
+    int rc = bwd_prologue(device);
+    if (rc) return rc;
+    if (!x || !w || !dy || !dw) return fail(nullptr, SR_ERR_ARG, "NULL tensor pointer");
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return fail(nullptr, SR_ERR_ARG, "non-positive dimension");
+    if (dtype != SR_FP32 && dtype != SR_BF16X3) return fail(nullptr, SR_ERR_ARG, "backward ops need dtype fp32 or bf16x3");
+    if (convt && dx && Cout % 64) return fail(nullptr, SR_ERR_ARG, "transposed-conv data gradient needs Cout to be a multiple of 64");
+    DevBufs d;
+    const size_t npix = (size_t)B * H * W, opix = convt ? 4 * npix : npix, nw = (size_t)9 * Cin * Cout;
+    float* d_x = d.put(x, npix * Cin);
+    float* d_dy = d.put(dy, opix * Cout);
+    float* d_w = d.put(w, nw);
+    float* d_dw = d.get(nw);
+    float* d_db = d.get(Cout);
+    float* d_part = d.get(wgrad_workspace_bytes(B, H, W, Cin, Cout, convt) / 4);
+    if (!d_x || !d_dy || !d_w || !d_dw || !d_db || !d_part) return fail(nullptr, SR_ERR_HIP, "hipMalloc / copy failed");
+    WgradArgs wa = {d_x, d_dy, d_part, d_dw, d_db, B, H, W, Cin, Cout, Cin, Cout, convt};
+    LAUNCHCHK(nullptr, "wgrad", launch_wgrad(wa, nullptr));
+    if (dx) {
+        float* d_dx = d.get(npix * Cin);
+        if (!d_dx) return fail(nullptr, SR_ERR_HIP, "hipMalloc failed");
+        if (convt) {
+            LAUNCHCHK(nullptr, "dgrad_s2", launch_dgrad_s2(d_dy, d_w, d_dx, B, H, W, Cin, Cout, Cout, Cin, nullptr));
+        } else {
+            ConvLayer D;
+            plan_layer(D, dtype, M_CONV, Cout, Cin);
+            struct Guard { ConvLayer& l; ~Guard() { free_layer(l); } } guard{D};
+            if ((rc = upload_layer(nullptr, D, dtype, w, nullptr, PK_DGRAD))) return rc;
+            float* d_dyp = d.get(npix * D.cin_p);
+            if (!d_dyp) return fail(nullptr, SR_ERR_HIP, "hipMalloc failed");
+            LAUNCHCHK(nullptr, "pad_channels", launch_pad_channels(d_dy, d_dyp, 0, (long)npix, Cout, D.cin_p, nullptr));
+            rc = run_conv(nullptr, dtype, nullptr, D, B, {d_dyp, H, W, d_dx, Cin, Cin, 1, nullptr, 0, A_NONE}, "op_dgrad");
+            if (rc) return rc;
+            HIPCHK(nullptr, hipDeviceSynchronize());   // before the guard frees the weights
+        }
+        HIPCHK(nullptr, hipDeviceSynchronize());
+        HIPCHK(nullptr, hipMemcpy(dx, d_dx, npix * Cin * 4, hipMemcpyDeviceToHost));
+    }
+    HIPCHK(nullptr, hipDeviceSynchronize());
+    HIPCHK(nullptr, hipMemcpy(dw, d_dw, nw * 4, hipMemcpyDeviceToHost));
+    if (db) HIPCHK(nullptr, hipMemcpy(db, d_db, (size_t)Cout * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int sr_op_conv3x3_bwd(int device, int dtype, int B, int H, int W, int Cin, int Cout, const float* x, const float* w,
+                      const float* dy, float* dx, float* dw, float* db) {
+    return conv_bwd_op(device, dtype, 0, B, H, W, Cin, Cout, x, w, dy, dx, dw, db);
+}
+
+int sr_op_convT3x3s2_bwd(int device, int B, int H, int W, int Cin, int Cout, const float* x, const float* w,
+                         const float* dy, float* dx, float* dw, float* db) {
+    return conv_bwd_op(device, SR_FP32, 1, B, H, W, Cin, Cout, x, w, dy, dx, dw, db);
+}
+
+int sr_op_maxpool2_bwd(int device, int B, int H, int W, int C, const float* x, const float* gy, float* gx) {
+    int rc = bwd_prologue(device);
+    if (rc) return rc;
+    if (!x || !gy || !gx) return fail(nullptr, SR_ERR_ARG, "NULL tensor pointer");
+    if (B < 1 || H < 1 || W < 1 || C < 1) return fail(nullptr, SR_ERR_ARG, "non-positive dimension");
+    DevBufs d;
+    const size_t n = (size_t)B * H * W * C, no = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * C;
+    float *d_x = d.put(x, n), *d_gy = d.put(gy, no), *d_gx = d.get(n);
+    if (!d_x || !d_gy || !d_gx) return fail(nullptr, SR_ERR_HIP, "hipMalloc / copy failed");
+    LAUNCHCHK(nullptr, "maxpool2_bwd", launch_maxpool2_bwd(d_x, d_gy, d_gx, B, H, W, C, nullptr));
+    HIPCHK(nullptr, hipDeviceSynchronize());
+    HIPCHK(nullptr, hipMemcpy(gx, d_gx, n * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+int sr_op_resize_bilinear_bwd(int device, int B, int H, int W, int C, int s, const float* gy, float* gx) {
+    int rc = bwd_prologue(device);
+    if (rc) return rc;
+    if (!gy || !gx) return fail(nullptr, SR_ERR_ARG, "NULL tensor pointer");
+    if (B < 1 || H < 1 || W < 1 || C < 1 || s < 1) return fail(nullptr, SR_ERR_ARG, "non-positive dimension");
+    DevBufs d;
+    const size_t n = (size_t)B * H * W * C;
+    float *d_gy = d.put(gy, n * s * s), *d_gx = d.get(n);
+    if (!d_gy || !d_gx) return fail(nullptr, SR_ERR_HIP, "hipMalloc / copy failed");
+    LAUNCHCHK(nullptr, "resize_bwd", launch_resize_bwd(d_gy, d_gx, B, H, W, C, s, C, 0, nullptr));
+    HIPCHK(nullptr, hipDeviceSynchronize());
+    HIPCHK(nullptr, hipMemcpy(gx, d_gx, n * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+int sr_op_warp_bwd_flow(int device, int B, int H, int W, int C, const float* img, const float* flow, const float* g, float* gflow) {
+    int rc = bwd_prologue(device);
+    if (rc) return rc;
+    if (!img || !flow || !g || !gflow) return fail(nullptr, SR_ERR_ARG, "NULL tensor pointer");
+    if (B < 1 || H < 2 || W < 2 || C < 1) return fail(nullptr, SR_ERR_ARG, "dense_image_warp needs H, W >= 2");
+    DevBufs d;
+    const size_t npix = (size_t)B * H * W;
+    float *d_i = d.put(img, npix * C), *d_f = d.put(flow, npix * 2), *d_g = d.put(g, npix * C), *d_o = d.get(npix * 2);
+    if (!d_i || !d_f || !d_g || !d_o) return fail(nullptr, SR_ERR_HIP, "hipMalloc / copy failed");
+    LAUNCHCHK(nullptr, "warp_bwd_flow", launch_warp_bwd_flow(d_i, d_f, d_g, d_o, B, H, W, C, 2, 0, nullptr));
+    HIPCHK(nullptr, hipDeviceSynchronize());
+    HIPCHK(nullptr, hipMemcpy(gflow, d_o, npix * 2 * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+}  // extern "C"

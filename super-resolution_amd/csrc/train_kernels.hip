@@ -1,0 +1,542 @@
+// Backward kernels of the FRVSR training step (reference FRVSR.py:69-71,156: train_on_batch with two
+// MSE losses and Adam), gfx950.  All tensors are fp32 NHWC with explicit channel strides.
+//
+//   wgrad         kernel + bias gradient of Conv2D 3x3 / Conv2DTranspose 3x3 s2: a GEMM whose K dimension
+//                 is the PIXELS (v_mfma_f32_32x32x2_f32, two pixels per MFMA), so both operands are read
+//                 straight from the NHWC tensors, 32 consecutive channels of one pixel per half wave
+//                 (full 128-B lines, no staging); one wave owns a 32 x 32 block of (cin, cout) for all
+//                 9 taps (144 accumulator registers), slices of the pixel range go to different
+//                 workgroups and a second kernel sums the slices in a fixed order (deterministic).
+//   dgrad_s2      data gradient of Conv2DTranspose s2 = 3x3 stride-2 convolution of dY with the same
+//                 kernel; pixels are the M dimension, each lane streams 32 contiguous channels of its
+//                 pixel (one 128-B line) per tap, weights come from the Keras-layout tensor through L1.
+//   (the data gradient of the stride-1 convolutions runs on the forward MFMA kernel of conv_mfma.hip
+//    with mirrored, transposed weights: sr_api.hip pack_entries PK_DGRAD)
+//   act_bwd, maxpool2_bwd, resize_bwd, warp_bwd_flow, hr_warp_bwd, mse_grad: HBM-bound gathers
+//   adam, repack  optimizer update on the flat parameter vector and the re-pack of the updated
+//                 kernels into the MFMA fragment order of the forward / dgrad convolutions.
+#include "kernels.h"
+#include "gather_math.h"
+
+namespace sr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int blocks_for(long n, int bs) { return (int)((n + bs - 1) / bs); }
+
+// ================================================================== wgrad
+constexpr int WG_PART = 9 * 1024 + 64;   // floats of one (slice, block) partial: 9 taps x 32 x 32 + bias lanes
+
+struct WgradPlan {
+    int R, S;            // rows / columns of one tap's matrix: conv (cin, cout), transposed conv (cout, cin)
+    int nrb, ncolb, nblk, nbg, nslices;
+};
+
+static WgradPlan wgrad_plan(int B, int H, int W, int cin, int cout, int convt) {
+    WgradPlan p;
+    p.R = convt ? cout : cin;
+    p.S = convt ? cin : cout;
+    p.nrb = (p.R + 31) / 32;
+    p.ncolb = (p.S + 31) / 32;
+    p.nblk = p.nrb * p.ncolb;
+    p.nbg = (p.nblk + 3) / 4;
+    const long pairs = ((long)B * H * W + 1) / 2;
+    long ns = 1024 / p.nbg;                       // ~4 workgroups per CU
+    if (ns > pairs / 16) ns = pairs / 16;         // at least 16 MFMA k-steps per slice
+    if (ns < 1) ns = 1;
+    p.nslices = (int)ns;
+    return p;
+}
+
+size_t wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int convt) {
+    const WgradPlan p = wgrad_plan(B, H, W, cin, cout, convt);
+    return (size_t)p.nslices * p.nblk * WG_PART * sizeof(float);
+}
+
+template <int CONVT>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, const WgradPlan pl) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, kh = lane >> 5;
+    const int blk = (blockIdx.x % pl.nbg) * 4 + wave;
+    const int slice = blockIdx.x / pl.nbg;
+    if (blk >= pl.nblk) return;   // no barrier in this kernel
+    const int rb = blk / pl.ncolb, cb = blk - rb * pl.ncolb;
+    const int H = a.H, W = a.W;
+    const unsigned npix = (unsigned)a.B * H * W;
+    const unsigned pairs = (npix + 1) / 2;
+    const unsigned per = (pairs + pl.nslices - 1) / pl.nslices;
+    const unsigned q0 = slice * per, q1 = min(q0 + per, pairs);
+    // channel of this lane in the A (row) and B (column) operands
+    const int ch_a = rb * 32 + i, ch_b = cb * 32 + i;
+    const bool a_ok = ch_a < pl.R, b_ok = ch_b < pl.S;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+    for (unsigned q = q0; q < q1; ++q) {
+        const unsigned p = 2 * q + kh;
+        const bool valid = p < npix;
+        const int x = p % W;
+        const unsigned t1 = p / W;
+        const int y = t1 % H;
+        const int b = t1 / H;
+        float av[9], bv;
+        if constexpr (!CONVT) {
+            bv = (valid && b_ok) ? a.dy[(size_t)p * a.ycs + ch_b] : 0.f;
+            bsum += bv;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                const bool in = valid && a_ok && yy >= 0 && yy < H && xx >= 0 && xx < W;
+                av[t] = in ? a.x[(((size_t)b * H + yy) * W + xx) * a.xcs + ch_a] : 0.f;
+            }
+        } else {
+            bv = (valid && b_ok) ? a.x[(size_t)p * a.xcs + ch_b] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = 2 * y + t / 3, xx = 2 * x + t % 3;
+                const bool in = valid && a_ok && yy < 2 * H && xx < 2 * W;
+                av[t] = in ? a.dy[(((size_t)b * 2 * H + yy) * 2 * W + xx) * a.ycs + ch_a] : 0.f;
+            }
+            bsum += av[0] + av[1] + av[3] + av[4];   // the four phases cover every output pixel once
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
+    }
+    float* out = a.part + ((size_t)slice * pl.nblk + blk) * WG_PART;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 8 * (r >> 2) + 4 * kh + (r & 3);
+            out[t * 1024 + row * 32 + i] = acc[t][r];
+        }
+    out[9 * 1024 + lane] = bsum;
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                    const WgradPlan pl, int convt, int nbias) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nw = 9 * pl.R * pl.S;
+    if (idx >= nw + nbias) return;
+    const size_t stride = (size_t)pl.nblk * WG_PART;
+    if (idx < nw) {
+        const int tap = idx / (pl.R * pl.S);
+        const int rem = idx - tap * pl.R * pl.S;
+        const int r = rem / pl.S, s = rem - r * pl.S;
+        const int blk = (r >> 5) * pl.ncolb + (s >> 5);
+        const float* p = part + (size_t)blk * WG_PART + tap * 1024 + (r & 31) * 32 + (s & 31);
+        float sum = 0.f;
+        for (int sl = 0; sl < pl.nslices; ++sl) sum += p[sl * stride];
+        dw[idx] = sum;
+    } else if (db) {
+        const int c = idx - nw;
+        const int blk = convt ? (c >> 5) * pl.ncolb : (c >> 5);
+        const float* p = part + (size_t)blk * WG_PART + 9 * 1024 + (c & 31);
+        float sum = 0.f;
+        for (int sl = 0; sl < pl.nslices; ++sl) sum += p[sl * stride] + p[sl * stride + 32];
+        db[c] = sum;
+    }
+}
+
+hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
+    const WgradPlan pl = wgrad_plan(a.B, a.H, a.W, a.cin, a.cout, a.convt);
+    const dim3 grid(pl.nbg * pl.nslices), block(256);
+    if (a.convt)
+        hipLaunchKernelGGL(wgrad_kernel<1>, grid, block, 0, s, a, pl);
+    else
+        hipLaunchKernelGGL(wgrad_kernel<0>, grid, block, 0, s, a, pl);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int n = 9 * a.cin * a.cout + a.cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, a.part, a.dw, a.db, pl, a.convt, a.cout);
+    return hipGetLastError();
+}
+
+// ================================================================== dgrad of Conv2DTranspose s2
+// dX[y,x,ci] = sum_{ky,kx,co} dY[2y+ky, 2x+kx, co] * w[ky,kx,co,ci]     (dY = 0 outside [0,2H) x [0,2W))
+// K = cout in blocks of 64 (lane (pixel i, half kh) holds channels 32*kh .. 32*kh+31 of its pixel,
+// k-step s multiplies channel 32*kh + s), N = cin in blocks of NB*32 (blockIdx.y).
+template <int NB>
+__global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                       float* __restrict__ dx, int B, int H, int W, int K, int N,
+                                                       int ycs, int xcs) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, kh = lane >> 5;
+    const unsigned npix = (unsigned)B * H * W;
+    const unsigned p0 = (blockIdx.x * 4 + wave) * 32;
+    if (p0 >= npix) return;
+    const int n0 = blockIdx.y * NB * 32;
+    const unsigned p = p0 + i;
+    const bool valid = p < npix;
+    const int x = p % W;
+    const unsigned t1 = p / W;
+    const int y = t1 % H;
+    const int b = t1 / H;
+    f32x16 acc[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    for (int t = 0; t < 9; ++t) {
+        const int yy = 2 * y + t / 3, xx = 2 * x + t % 3;
+        const bool in = valid && yy < 2 * H && xx < 2 * W;
+        const float* src = dy + (((size_t)b * 2 * H + yy) * 2 * W + xx) * ycs + kh * 32;
+        for (int kc = 0; kc < K; kc += 64) {
+            f32x4 av[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                av[v] = in ? *reinterpret_cast<const f32x4*>(src + kc + 4 * v) : z;
+            }
+            const float* wr = w + ((size_t)t * K + kc + kh * 32) * N + n0 + i;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    const float bv = (n0 + n * 32 + i < N) ? wr[(size_t)s * N + n * 32] : 0.f;
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s >> 2][s & 3], bv, acc[n], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned row = p0 + 8 * (r >> 2) + 4 * kh + (r & 3);
+            const int ch = n0 + n * 32 + i;
+            if (row < npix && ch < N) dx[(size_t)row * xcs + ch] = acc[n][r];
+        }
+}
+
+hipError_t launch_dgrad_s2(const float* dy, const float* w, float* dx, int B, int H, int W, int cin, int cout,
+                           int ycs, int xcs, hipStream_t s) {
+    if (cout % 64 || ycs % 4) return hipErrorInvalidValue;
+    const long npix = (long)B * H * W;
+    const dim3 block(256);
+    if (cin > 32) {
+        const dim3 grid(blocks_for(npix, 128), (cin + 63) / 64);
+        hipLaunchKernelGGL(dgrad_s2_kernel<2>, grid, block, 0, s, dy, w, dx, B, H, W, cout, cin, ycs, xcs);
+    } else {
+        const dim3 grid(blocks_for(npix, 128), 1);
+        hipLaunchKernelGGL(dgrad_s2_kernel<1>, grid, block, 0, s, dy, w, dx, B, H, W, cout, cin, ycs, xcs);
+    }
+    return hipGetLastError();
+}
+
+// ================================================================== activation derivative from the OUTPUT
+// g[p, c] *= act'(.) expressed through y = act(.):  ReLU y > 0; LeakyReLU(0.2) y > 0 ? 1 : 0.2;
+// tanh 1 - y^2; clip[0,1] 0 < y < 1  (Keras / TF and torch agree away from the kinks)
+__global__ void act_bwd_kernel(float* __restrict__ g, const float* __restrict__ y, int act, long n, int C, int gcs, int ycs) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const long p = idx / C;
+    const int c = idx - p * C;
+    const float v = y[p * ycs + c];
+    float d = 1.f;
+    if (act == A_RELU) d = v > 0.f ? 1.f : 0.f;
+    else if (act == A_LRELU) d = v > 0.f ? 1.f : 0.2f;
+    else if (act == A_TANH) d = 1.f - v * v;
+    else if (act == A_CLIP01) d = (v > 0.f && v < 1.f) ? 1.f : 0.f;
+    g[p * gcs + c] *= d;
+}
+
+hipError_t launch_act_bwd(float* g, const float* y, int act, long npix, int C, int gcs, int ycs, hipStream_t s) {
+    const long n = npix * C;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, g, y, act, n, C, gcs, ycs);
+    return hipGetLastError();
+}
+
+// ================================================================== MaxPool2D 2x2 SAME backward
+// the gradient goes to the first maximum of the window in row-major order (TF MaxPoolGrad, torch)
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx,
+                                    int B, int H, int W, int C) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long total = (long)B * Ho * Wo * C;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % C;
+    long p = idx / C;
+    const int ox = p % Wo;
+    p /= Wo;
+    const int oy = p % Ho;
+    const int b = p / Ho;
+    const float g = gy[idx];
+    int best = -1;
+    float bv = 0.f;
+    for (int k = 0; k < 4; ++k) {
+        const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
+        if (yy >= H || xx >= W) continue;
+        const float v = x[(((size_t)b * H + yy) * W + xx) * C + c];
+        if (best < 0 || v > bv) {
+            best = k;
+            bv = v;
+        }
+    }
+    for (int k = 0; k < 4; ++k) {
+        const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
+        if (yy >= H || xx >= W) continue;
+        gx[(((size_t)b * H + yy) * W + xx) * C + c] = k == best ? g : 0.f;
+    }
+}
+
+hipError_t launch_maxpool2_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, hipStream_t s) {
+    const long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * C;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, x, gy, gx, B, H, W, C);
+    return hipGetLastError();
+}
+
+// ================================================================== adjoint of the TF1-legacy bilinear resize
+// forward: out[Y] = in[lo] + (in[hi] - in[lo]) * t, lo = Y / s, hi = min(lo + 1, n - 1), t = (Y % s) / s.
+// gather form: input row y collects weight (1 - t) from the s output rows of its own block, t from the
+// block above (whose hi is y), and t again from its own block when y is the last row (hi clamps to y).
+__device__ __forceinline__ float resize_adj_weight(int Y, int y, int n, int s) {
+    const int lo = Y / s;
+    const float t = (float)(Y - lo * s) / (float)s;
+    float w = 0.f;
+    if (lo == y) w += 1.f - t;
+    if (min(lo + 1, n - 1) == y) w += t;
+    return w;
+}
+
+__global__ void resize_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int B, int H, int W, int C,
+                                  int s, int ocs, int accumulate) {
+    const long total = (long)B * H * W * C;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % C;
+    long p = idx / C;
+    const int x = p % W;
+    p /= W;
+    const int y = p % H;
+    const int b = p / H;
+    const int Ho = s * H, Wo = s * W;
+    const int Y0 = max(0, s * (y - 1)), Y1 = min(Ho, s * (y + 1));
+    const int X0 = max(0, s * (x - 1)), X1 = min(Wo, s * (x + 1));
+    float sum = 0.f;
+    for (int Y = Y0; Y < Y1; ++Y) {
+        const float wy = resize_adj_weight(Y, y, H, s);
+        float row = 0.f;
+        for (int X = X0; X < X1; ++X)
+            row += resize_adj_weight(X, x, W, s) * gy[(((size_t)b * Ho + Y) * Wo + X) * C + c];
+        sum += wy * row;
+    }
+    float* o = gx + (((size_t)b * H + y) * W + x) * ocs + c;
+    *o = accumulate ? *o + sum : sum;
+}
+
+hipError_t launch_resize_bwd(const float* gy, float* gx, int B, int H, int W, int C, int sc, int ocs, int accumulate,
+                             hipStream_t s) {
+    const long total = (long)B * H * W * C;
+    hipLaunchKernelGGL(resize_bwd_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, gy, gx, B, H, W, C, sc, ocs, accumulate);
+    return hipGetLastError();
+}
+
+// ================================================================== dense_image_warp, gradient w.r.t. the flow
+// out = ay*(bot - top) + top, top = ax*(tr - tl) + tl, bot = ax*(br - bl) + bl, a = clamp(q - floor, 0, 1),
+// q = coordinate - flow: d out / d flow_y = -(bot - top), d out / d flow_x = -((1-ay)(tr-tl) + ay(br-bl)),
+// passed where the clamp is inactive (0 <= q - floor <= 1, inclusive like tf.clip_by_value / torch.clamp);
+// the floor and its clamp have zero gradient, the image is a constant input (reference FRVSR.py:154).
+struct WarpGrad {
+    float gy, gx;
+};
+__device__ __forceinline__ void warp_grad_acc(WarpGrad& o, float g, float tl, float tr, float bl, float br, float ax, float ay) {
+    const float top = ax * (tr - tl) + tl;
+    const float bot = ax * (br - bl) + bl;
+    o.gy -= g * (bot - top);
+    o.gx -= g * ((1.f - ay) * (tr - tl) + ay * (br - bl));
+}
+__device__ __forceinline__ bool warp_pass(float q, int n) {
+    float f = floorf(q);
+    f = fminf(fmaxf(f, 0.f), (float)(n - 2));
+    const float d = q - f;
+    return d >= 0.f && d <= 1.f;
+}
+
+__global__ void warp_bwd_flow_kernel(const float* __restrict__ img, const float* __restrict__ flow, const float* __restrict__ g,
+                                     float* __restrict__ gflow, int B, int H, int W, int C, int gfs, int accumulate) {
+    const long npix = (long)B * H * W;
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const int x = p % W;
+    long q = p / W;
+    const int y = q % H;
+    const int b = q / H;
+    const float2 f = *reinterpret_cast<const float2*>(flow + p * 2);
+    const float qy = (float)y - f.x, qx = (float)x - f.y;
+    const WarpCoord cy = warp_coord(qy, H);
+    const WarpCoord cx = warp_coord(qx, W);
+    const float* r0 = img + (((size_t)b * H + cy.f) * W + cx.f) * C;
+    const float* r1 = r0 + (size_t)W * C;
+    WarpGrad o = {0.f, 0.f};
+    for (int c = 0; c < C; ++c) warp_grad_acc(o, g[p * C + c], r0[c], r0[C + c], r1[c], r1[C + c], cx.a, cy.a);
+    if (!warp_pass(qy, H)) o.gy = 0.f;
+    if (!warp_pass(qx, W)) o.gx = 0.f;
+    float* out = gflow + p * gfs;
+    out[0] = accumulate ? out[0] + o.gy : o.gy;
+    out[1] = accumulate ? out[1] + o.gx : o.gx;
+}
+
+hipError_t launch_warp_bwd_flow(const float* img, const float* flow, const float* g, float* gflow, int B, int H, int W,
+                                int C, int gfs, int accumulate, hipStream_t s) {
+    const long npix = (long)B * H * W;
+    hipLaunchKernelGGL(warp_bwd_flow_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, s, img, flow, g, gflow, B, H, W, C, gfs, accumulate);
+    return hipGetLastError();
+}
+
+// HR warp of pre_srnet (fused_ops.hip): the gradient of SRNet's input channels 3 + (dy*4+dx)*3 + c
+// (space_to_depth order, reference layers.py:109) w.r.t. F_HR at HR pixel (4y+dy, 4x+dx), F_HR being
+// recomputed from the LR flow with the forward's arithmetic so that every floor falls the same way.
+__global__ void hr_warp_bwd_kernel(const float* __restrict__ est, const float* __restrict__ flow, const float* __restrict__ g_sin,
+                                   float* __restrict__ g_fhr, int B, int H, int W, int gcs) {
+    const int HH = 4 * H, WW = 4 * W;
+    const long npix = (long)B * HH * WW;
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const int X = p % WW;
+    long q = p / WW;
+    const int Y = q % HH;
+    const int b = q / HH;
+    const int y = Y >> 2, x = X >> 2, dy = Y & 3, dx = X & 3;
+    const int x1 = min(x + 1, W - 1), y1 = min(y + 1, H - 1);
+    const float* fb = flow + (size_t)b * H * W * 2;
+    const float2 ftl = *reinterpret_cast<const float2*>(fb + ((size_t)y * W + x) * 2);
+    const float2 ftr = *reinterpret_cast<const float2*>(fb + ((size_t)y * W + x1) * 2);
+    const float2 fbl = *reinterpret_cast<const float2*>(fb + ((size_t)y1 * W + x) * 2);
+    const float2 fbr = *reinterpret_cast<const float2*>(fb + ((size_t)y1 * W + x1) * 2);
+    const float ty = dy * 0.25f, tx = dx * 0.25f;
+    const float fy = lerp2(ftl.x, ftr.x, fbl.x, fbr.x, tx, ty);
+    const float fx = lerp2(ftl.y, ftr.y, fbl.y, fbr.y, tx, ty);
+    const float qy = (float)Y - fy, qx = (float)X - fx;
+    const WarpCoord cy = warp_coord(qy, HH);
+    const WarpCoord cx = warp_coord(qx, WW);
+    const float* r0 = est + (((size_t)b * HH + cy.f) * WW + cx.f) * 3;
+    const float* r1 = r0 + (size_t)WW * 3;
+    const float* g = g_sin + (((size_t)b * H + y) * W + x) * gcs + 3 + (dy * 4 + dx) * 3;
+    WarpGrad o = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) warp_grad_acc(o, g[c], r0[c], r0[3 + c], r1[c], r1[3 + c], cx.a, cy.a);
+    if (!warp_pass(qy, HH)) o.gy = 0.f;
+    if (!warp_pass(qx, WW)) o.gx = 0.f;
+    *reinterpret_cast<float2*>(g_fhr + p * 2) = make_float2(o.gy, o.gx);
+}
+
+hipError_t launch_hr_warp_bwd(const float* est_prev, const float* flow, const float* g_sin, float* g_fhr, int B, int H, int W,
+                              int gcs, hipStream_t s) {
+    const long npix = (long)B * H * W * 16;
+    hipLaunchKernelGGL(hr_warp_bwd_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, s, est_prev, flow, g_sin, g_fhr, B, H, W, gcs);
+    return hipGetLastError();
+}
+
+// ================================================================== mean-squared-error loss and its gradient
+// Keras: mean over every element (reference FRVSR.py:70).  g[p, c < C] = scale * (pred - target) (zeroed
+// where clip01_mask and pred sits on a clip bound: the gradient of SRNet's final clip), g[p, C..gcs) = 0;
+// partial[block] = sum (pred - target)^2 of the block's elements.
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                       float* __restrict__ g, double* __restrict__ partial, long npix, int C,
+                                                       int gcs, float scale, int clip01_mask) {
+    __shared__ double red[256];
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    double sq = 0.0;
+    if (idx < npix * gcs) {
+        const long p = idx / gcs;
+        const int c = idx - p * gcs;
+        float gv = 0.f;
+        if (c < C) {
+            const float a = pred[p * C + c];
+            const float d = a - target[p * C + c];
+            sq = (double)d * d;
+            gv = scale * d;
+            if (clip01_mask && !(a > 0.f && a < 1.f)) gv = 0.f;
+        }
+        g[idx] = gv;
+    }
+    red[threadIdx.x] = sq;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int n, double inv_count, float* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = (float)(red[0] * inv_count);
+}
+
+size_t mse_workspace_bytes(long npix, int gcs) { return (size_t)blocks_for(npix * gcs, 256) * sizeof(double); }
+
+hipError_t launch_mse_grad(const float* pred, const float* target, float* g, double* partial, float* loss_out, long npix, int C,
+                           int gcs, int clip01_mask, hipStream_t s) {
+    const int nb = blocks_for(npix * gcs, 256);
+    const double count = (double)npix * C;
+    hipLaunchKernelGGL(mse_grad_kernel, dim3(nb), dim3(256), 0, s, pred, target, g, partial, npix, C, gcs, (float)(2.0 / count), clip01_mask);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, nb, 1.0 / count, loss_out);
+    return hipGetLastError();
+}
+
+// ================================================================== Adam (Keras 2.2.4 optimizers.py) and re-pack
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
+                            long n, float lr_t, float b1, float b2, float eps, float gscale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+}
+
+hipError_t launch_adam(float* p, float* m, float* v, const float* g, long n, float lr_t, float b1, float b2, float eps,
+                       float gscale, hipStream_t s) {
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, p, m, v, g, n, lr_t, b1, b2, eps, gscale);
+    return hipGetLastError();
+}
+
+// packed[dst] = kernel[src] for the listed elements (padding zeros never change); bf16 rounds to nearest
+// even exactly like the host packer, bf16x3 also writes the residual 64 vectors further on
+__device__ __forceinline__ unsigned short f2bf_dev(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__global__ void repack_kernel(const float* __restrict__ kernel, const int2* __restrict__ ents, int n, void* __restrict__ out, int prec) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int2 e = ents[i];
+    const float v = kernel[e.x];
+    const unsigned dst = (unsigned)e.y;
+    if (prec == P_FP32) {
+        reinterpret_cast<float*>(out)[dst] = v;
+    } else {
+        unsigned short* o = reinterpret_cast<unsigned short*>(out);
+        const unsigned short hi = f2bf_dev(v);
+        o[dst] = hi;
+        if (prec == P_BF16X3) o[dst + 512] = f2bf_dev(v - __uint_as_float((unsigned)hi << 16));
+    }
+}
+
+hipError_t launch_repack(const float* kernel, const void* ents, int n, void* out, int prec, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(repack_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, kernel, (const int2*)ents, n, out, prec);
+    return hipGetLastError();
+}
+
+}  // namespace sr

@@ -52,6 +52,18 @@ SIGNATURES = {
     "sr_op_resize_bilinear": (C.c_int, [C.c_int] * 6 + [_vp, _vp]),
     "sr_op_warp": (C.c_int, [C.c_int] * 5 + [_vp, _vp, _vp]),
     "sr_op_space_to_depth": (C.c_int, [C.c_int] * 6 + [_vp, _vp]),
+    "sr_train_param_count": (C.c_int, [_vp, _i64p]),
+    "sr_train_grads": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _f32p]),
+    "sr_train_grads_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _f32p]),
+    "sr_train_read_grads": (C.c_int, [_vp, _vp]),
+    "sr_train_apply": (C.c_int, [_vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "sr_train_on_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_float, _f32p]),
+    "sr_train_iterations": (C.c_int64, [_vp]),
+    "sr_op_conv3x3_bwd": (C.c_int, [C.c_int] * 7 + [_vp] * 6),
+    "sr_op_convT3x3s2_bwd": (C.c_int, [C.c_int] * 6 + [_vp] * 6),
+    "sr_op_maxpool2_bwd": (C.c_int, [C.c_int] * 5 + [_vp] * 3),
+    "sr_op_resize_bilinear_bwd": (C.c_int, [C.c_int] * 6 + [_vp] * 2),
+    "sr_op_warp_bwd_flow": (C.c_int, [C.c_int] * 5 + [_vp] * 4),
     "sr_bench_conv": (C.c_int, [C.c_int] * 10 + [C.POINTER(C.c_float)]),
 }
 
@@ -219,6 +231,52 @@ class Context:
         _check(lib().sr_srnet(self._h, B, _ptr(lr_t), _ptr(s_s), _ptr(out)), self._h)
         return out
 
+    # -- training (reference FRVSR.py:69-71,156)
+    def param_count(self):
+        n = C.c_int64()
+        _check(lib().sr_train_param_count(self._h, C.byref(n)), self._h)
+        return n.value
+
+    def _train_inputs(self, lr_t, lr_tm1, est_tm1, hr_t):
+        B = int(np.shape(lr_t)[0])
+        ls, hs = self._shapes(B)
+        return (B, self._check_in(lr_t, ls, "I_LR_t"), self._check_in(lr_tm1, ls, "I_LR_t_1"),
+                self._check_in(est_tm1, hs, "I_est_t_1"), self._check_in(hr_t, hs, "I_HR_t"))
+
+    def train_grads(self, lr_t, lr_tm1, est_tm1, hr_t, d_grads=None, read=False):
+        """Forward + backward of one batch.  d_grads: optional DEVICE pointer (int) that receives the flat
+        gradient (the all-reduce buffer).  Returns [total, sr_loss, flow_loss] (+ the flat gradient as a
+        numpy array when read=True)."""
+        B, a, b, c, d = self._train_inputs(lr_t, lr_tm1, est_tm1, hr_t)
+        losses = (C.c_float * 3)()
+        _check(lib().sr_train_grads(self._h, B, _ptr(a), _ptr(b), _ptr(c), _ptr(d),
+                                    _vp(d_grads) if d_grads else None, losses), self._h)
+        if not read:
+            return list(losses)
+        g = np.empty(self.param_count(), np.float32)
+        _check(lib().sr_train_read_grads(self._h, _ptr(g)), self._h)
+        return list(losses), g
+
+    def train_apply(self, d_grads=None, grad_scale=1.0, lr=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        _check(lib().sr_train_apply(self._h, _vp(d_grads) if d_grads else None, grad_scale, lr, beta_1, beta_2, epsilon), self._h)
+
+    def train_on_batch(self, lr_t, lr_tm1, est_tm1, hr_t, lr=1e-4):
+        B, a, b, c, d = self._train_inputs(lr_t, lr_tm1, est_tm1, hr_t)
+        losses = (C.c_float * 3)()
+        _check(lib().sr_train_on_batch(self._h, B, _ptr(a), _ptr(b), _ptr(c), _ptr(d), lr, losses), self._h)
+        return list(losses)
+
+    def train_iterations(self):
+        return int(lib().sr_train_iterations(self._h))
+
+    def split_grads(self, flat):
+        """flat gradient / parameter vector -> {keras name: array} in file order."""
+        out, o = {}, 0
+        for name, a in self.get_weights():
+            out[name] = np.asarray(flat[o:o + a.size]).reshape(a.shape)
+            o += a.size
+        return out
+
     # -- profiling
     def profile_enable(self, on=True):
         _check(lib().sr_profile_enable(self._h, 1 if on else 0), self._h)
@@ -297,6 +355,57 @@ def space_to_depth(x, bs=4, device=0):
         raise ValueError("space_to_depth: H and W must be multiples of the block size")
     out = np.empty((B, H // bs, W // bs, bs * bs * Cc), np.float32)
     _check(lib().sr_op_space_to_depth(device, B, H, W, Cc, bs, _ptr(x), _ptr(out)))
+    return out
+
+
+# ---------------------------------------------------------------- gradients of the single ops
+def conv3x3_bwd(x, w, dy, dtype="fp32", want_dx=True, device=0):
+    x, w, dy = _f32(x), _f32(w), _f32(dy)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[3]
+    if w.shape != (3, 3, Cin, Cout) or dy.shape != (B, H, W, Cout):
+        raise ValueError(f"kernel {w.shape} / dy {dy.shape} do not match x {x.shape}")
+    dx = np.empty_like(x) if want_dx else None
+    dw, db = np.empty_like(w), np.empty(Cout, np.float32)
+    _check(lib().sr_op_conv3x3_bwd(device, DTYPES[dtype], B, H, W, Cin, Cout, _ptr(x), _ptr(w), _ptr(dy),
+                                   _ptr(dx) if want_dx else None, _ptr(dw), _ptr(db)))
+    return dx, dw, db
+
+
+def conv_transpose3x3_s2_bwd(x, w, dy, want_dx=True, device=0):
+    x, w, dy = _f32(x), _f32(w), _f32(dy)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[2]
+    if w.shape != (3, 3, Cout, Cin) or dy.shape != (B, 2 * H, 2 * W, Cout):
+        raise ValueError(f"kernel {w.shape} / dy {dy.shape} do not match x {x.shape}")
+    dx = np.empty_like(x) if want_dx else None
+    dw, db = np.empty_like(w), np.empty(Cout, np.float32)
+    _check(lib().sr_op_convT3x3s2_bwd(device, B, H, W, Cin, Cout, _ptr(x), _ptr(w), _ptr(dy),
+                                      _ptr(dx) if want_dx else None, _ptr(dw), _ptr(db)))
+    return dx, dw, db
+
+
+def maxpool2_bwd(x, gy, device=0):
+    x, gy = _f32(x), _f32(gy)
+    B, H, W, Cc = x.shape
+    gx = np.empty_like(x)
+    _check(lib().sr_op_maxpool2_bwd(device, B, H, W, Cc, _ptr(x), _ptr(gy), _ptr(gx)))
+    return gx
+
+
+def resize_bilinear_bwd(gy, s, device=0):
+    gy = _f32(gy)
+    B, Ho, Wo, Cc = gy.shape
+    gx = np.empty((B, Ho // s, Wo // s, Cc), np.float32)
+    _check(lib().sr_op_resize_bilinear_bwd(device, B, Ho // s, Wo // s, Cc, s, _ptr(gy), _ptr(gx)))
+    return gx
+
+
+def warp_bwd_flow(img, flow, g, device=0):
+    img, flow, g = _f32(img), _f32(flow), _f32(g)
+    B, H, W, Cc = img.shape
+    out = np.empty((B, H, W, 2), np.float32)
+    _check(lib().sr_op_warp_bwd_flow(device, B, H, W, Cc, _ptr(img), _ptr(flow), _ptr(g), _ptr(out)))
     return out
 
 

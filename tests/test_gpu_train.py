@@ -1,0 +1,241 @@
+"""GPU parity of the training step (SURVEY.md section 8 f rank 1; reference FRVSR.py:69-71,156) through the
+C ABI against torch autograd over the CPU oracle (oracle/ref_train.py, float64).
+
+Bars, stated per test: single-op gradients max-abs error <= 2e-4 of the tensor's max-abs (fp32 MFMA
+accumulates thousands of products; bf16x3 data gradients get 5e-4); whole-step gradients <= 2e-3
+relative to each tensor's max-abs gradient (fp32) / 5e-3 (bf16x3), losses to 1e-5 relative; two Adam
+steps move every weight like Keras 2.2.4's Adam to within 2 % of the step size.  Parity is unpinned by the
+reference itself (no Keras / TF here), exactly as for the forward path."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_numpy as rn
+from oracle import ref_torch as rt
+from oracle import ref_train
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sh():
+    import sr_hip
+    assert sr_hip.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    return sr_hip
+
+
+def rnd(seed, *shape, lo=-1.0, hi=1.0):
+    n = int(np.prod(shape))
+    return (rn.uniform01(seed, n).reshape(shape) * (hi - lo) + lo).astype(np.float32)
+
+
+def rel_err(got, want):
+    return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+def t64(a):
+    return torch.tensor(np.asarray(a, np.float64))
+
+
+# ------------------------------------------------------------------ single ops
+CONV_BWD = [  # B, H, W, Cin, Cout
+    (2, 16, 16, 64, 64), (1, 9, 35, 6, 32), (1, 24, 40, 32, 64), (1, 3, 5, 256, 128), (2, 8, 8, 128, 256),
+    (1, 16, 24, 51, 64), (1, 32, 32, 64, 3), (1, 8, 40, 32, 2), (1, 5, 7, 5, 7), (3, 7, 9, 48, 96),
+]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", CONV_BWD)
+def test_conv3x3_bwd(sh, B, H, W, Cin, Cout, dtype):
+    x, w, dy = rnd(1, B, H, W, Cin), rnd(2, 3, 3, Cin, Cout, lo=-0.2, hi=0.2), rnd(3, B, H, W, Cout)
+    xt = t64(x).permute(0, 3, 1, 2).requires_grad_(True)
+    wt = t64(w).requires_grad_(True)
+    bt = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xt, wt.permute(3, 2, 0, 1), bt, padding=1)
+    y.backward(t64(dy).permute(0, 3, 1, 2))
+    dx, dw, db = sh.conv3x3_bwd(x, w, dy, dtype=dtype)
+    assert rel_err(dw, wt.grad.numpy()) <= 2e-4
+    assert rel_err(db, bt.grad.numpy()) <= 2e-4
+    assert rel_err(dx, xt.grad.permute(0, 2, 3, 1).numpy()) <= (2e-4 if dtype == "fp32" else 5e-4)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 8, 8, 64, 64), (1, 5, 7, 64, 64), (1, 16, 12, 32, 64), (1, 4, 36, 64, 128)])
+def test_conv_transpose_bwd(sh, B, H, W, Cin, Cout):
+    x, w, dy = rnd(4, B, H, W, Cin), rnd(5, 3, 3, Cout, Cin, lo=-0.2, hi=0.2), rnd(6, B, 2 * H, 2 * W, Cout)
+    xt = t64(x).permute(0, 3, 1, 2).requires_grad_(True)
+    wt = t64(w).requires_grad_(True)
+    bt = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = rt.conv_transpose3x3_s2_same(xt, wt.permute(3, 2, 0, 1), bt)
+    y.backward(t64(dy).permute(0, 3, 1, 2))
+    dx, dw, db = sh.conv_transpose3x3_s2_bwd(x, w, dy)
+    assert rel_err(dw, wt.grad.numpy()) <= 2e-4
+    assert rel_err(db, bt.grad.numpy()) <= 2e-4
+    assert rel_err(dx, xt.grad.permute(0, 2, 3, 1).numpy()) <= 2e-4
+
+
+def test_conv_transpose_bwd_rejects_unsupported(sh):
+    x, w, dy = rnd(1, 1, 4, 4, 8), rnd(2, 3, 3, 24, 8), rnd(3, 1, 8, 8, 24)
+    with pytest.raises(ValueError):
+        sh.conv_transpose3x3_s2_bwd(x, w, dy)          # data gradient needs Cout % 64 == 0
+    _, dw, _ = sh.conv_transpose3x3_s2_bwd(x, w, dy, want_dx=False)   # the weight gradient has no such limit
+    xt = t64(x).permute(0, 3, 1, 2)
+    wt = t64(w).requires_grad_(True)
+    rt.conv_transpose3x3_s2_same(xt, wt.permute(3, 2, 0, 1), torch.zeros(24, dtype=torch.float64)).backward(t64(dy).permute(0, 3, 1, 2))
+    assert rel_err(dw, wt.grad.numpy()) <= 2e-4
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 32), (1, 7, 9, 5), (1, 24, 40, 64)])
+def test_maxpool2_bwd(sh, B, H, W, C):
+    x, gy = rnd(7, B, H, W, C), rnd(8, B, (H + 1) // 2, (W + 1) // 2, C)
+    xt = t64(x).permute(0, 3, 1, 2).requires_grad_(True)
+    rt.maxpool2_same(xt).backward(t64(gy).permute(0, 3, 1, 2))
+    gx = sh.maxpool2_bwd(x, gy)
+    assert np.array_equal(gx, xt.grad.permute(0, 2, 3, 1).numpy().astype(np.float32))   # a routing, exact
+
+
+def test_maxpool2_bwd_ties_go_to_the_first_maximum(sh):
+    x = np.zeros((1, 4, 4, 1), np.float32)              # every window is a four-way tie
+    gy = np.arange(1, 5, dtype=np.float32).reshape(1, 2, 2, 1)
+    gx = sh.maxpool2_bwd(x, gy)[0, :, :, 0]
+    want = np.zeros((4, 4), np.float32)
+    want[0, 0], want[0, 2], want[2, 0], want[2, 2] = 1, 2, 3, 4
+    assert np.array_equal(gx, want)
+
+
+@pytest.mark.parametrize("B,H,W,C,s", [(1, 4, 4, 2, 4), (2, 8, 8, 2, 4), (1, 3, 5, 256, 2), (2, 6, 10, 64, 2), (1, 1, 1, 3, 2)])
+def test_resize_bilinear_bwd(sh, B, H, W, C, s):
+    gy = rnd(9, B, s * H, s * W, C)
+    xt = torch.zeros(B, C, H, W, dtype=torch.float64, requires_grad=True)
+    rt.resize_bilinear_legacy(xt, s).backward(t64(gy).permute(0, 3, 1, 2))
+    gx = sh.resize_bilinear_bwd(gy, s)
+    assert np.abs(gx - xt.grad.permute(0, 2, 3, 1).numpy()).max() <= 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,C,amp", [(2, 16, 16, 3, 1.0), (1, 9, 12, 3, 6.0), (1, 64, 64, 3, 0.3), (1, 8, 8, 5, 20.0)])
+def test_warp_bwd_flow(sh, B, H, W, C, amp):
+    img, g = rnd(10, B, H, W, C, lo=0.0), rnd(11, B, H, W, C)
+    flow = rnd(12, B, H, W, 2, lo=-amp, hi=amp)          # large amplitudes leave the image: clamped, zero gradient
+    ft = t64(flow).permute(0, 3, 1, 2).requires_grad_(True)
+    rt.dense_image_warp(t64(img).permute(0, 3, 1, 2), ft).backward(t64(g).permute(0, 3, 1, 2))
+    want = ft.grad.permute(0, 2, 3, 1).numpy()
+    got = sh.warp_bwd_flow(img, flow, g)
+    # a query within an ulp of a pixel centre may floor differently in float32 and float64: allow a
+    # handful of such pixels, everything else must agree
+    bad = np.abs(got - want).max(axis=-1) > 1e-4 * max(1.0, np.abs(want).max())
+    assert bad.mean() <= 1e-3
+
+
+# ------------------------------------------------------------------ whole step
+def step_data(seed, B, h, w):
+    rng = np.random.default_rng(seed)
+    lr_t = rng.random((B, h, w, 3), dtype=np.float32)
+    lr_tm1 = np.clip(lr_t + 0.1 * rng.standard_normal((B, h, w, 3)).astype(np.float32), 0, 1)
+    est = rng.random((B, 4 * h, 4 * w, 3), dtype=np.float32)
+    hr = rng.random((B, 4 * h, 4 * w, 3), dtype=np.float32)
+    return lr_t, lr_tm1, est, hr
+
+
+def check_grads(ctx, flat, want, tol):
+    got = ctx.split_grads(flat)
+    worst = ("", 0.0)
+    for name, g in want.items():
+        e = rel_err(got[name], g)
+        if e > worst[1]:
+            worst = (name, e)
+    assert worst[1] <= tol, f"gradient of {worst[0]}: relative error {worst[1]:.2e} > {tol}"
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-3), ("bf16x3", 5e-3)])
+@pytest.mark.parametrize("B,h,w", [(2, 16, 16), (1, 24, 40), (3, 32, 8)])
+def test_step_gradients_match_autograd(sh, weights7, B, h, w, dtype, tol):
+    data = step_data(100 + h, B, h, w)
+    want_l, want_g, _ = ref_train.loss_and_grads(weights7, *data)
+    ctx = sh.Context(h, w, max_batch=B, dtype=dtype)
+    ctx.load_weights(weights7)
+    losses, flat = ctx.train_grads(*data, read=True)
+    assert flat.size == ctx.param_count() == 2589093
+    assert np.allclose(losses, want_l, rtol=1e-4 if dtype == "fp32" else 1e-3)
+    check_grads(ctx, flat, want_g, tol)
+    # a smaller batch on the same ctx (buffers sized for max_batch) and determinism of the reductions
+    if B > 1:
+        sub = tuple(a[:1] for a in data)
+        _, g1 = ctx.train_grads(*sub, read=True)
+        _, g2 = ctx.train_grads(*sub, read=True)
+        assert np.array_equal(g1, g2)
+        _, want_sub, _ = ref_train.loss_and_grads(weights7, *sub)
+        check_grads(ctx, g1, want_sub, tol)
+    ctx.close()
+
+
+def test_zero_state_first_frame_gradients(sh, weights7):
+    """Frame 0 of a training clip: previous LR and estimate are zeros (reference FRVSR.py:124-125), so
+    every warp query sits exactly on a pixel centre -- the inclusive clamp passes the gradient there."""
+    lr_t, _, _, hr = step_data(5, 2, 16, 16)
+    z_lr, z_hr = np.zeros_like(lr_t), np.zeros_like(hr)
+    want_l, want_g, _ = ref_train.loss_and_grads(weights7, lr_t, z_lr, z_hr, hr)
+    ctx = sh.Context(16, 16, max_batch=2, dtype="fp32")
+    ctx.load_weights(weights7)
+    losses, flat = ctx.train_grads(lr_t, z_lr, z_hr, hr, read=True)
+    assert np.allclose(losses, want_l, rtol=1e-4)
+    check_grads(ctx, flat, want_g, 2e-3)
+    ctx.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_train_on_batch_follows_keras_adam(sh, weights7, dtype):
+    B, h, w = 2, 16, 16
+    ctx = sh.Context(h, w, max_batch=B, dtype=dtype)
+    ctx.load_weights(weights7)
+    opt = ref_train.KerasAdam(lr=1e-4)
+    ref_w = dict(weights7)
+    for it in range(2):
+        data = step_data(200 + it, B, h, w)
+        ref_w, want_l = ref_train.train_on_batch(ref_w, opt, *data)
+        losses = ctx.train_on_batch(*data, lr=1e-4)
+        assert np.allclose(losses, want_l, rtol=2e-3)
+    assert ctx.train_iterations() == 2
+    got = dict(ctx.get_weights())                         # save_weights sees the device master weights
+    for name, a in ref_w.items():
+        moved = np.abs(a - weights7[name]).max()
+        assert moved > 0
+        # Adam's first steps move every weight by ~lr whatever the gradient's size, so an element whose
+        # gradient is below the arithmetic's error can land anywhere within the step: compare statistics
+        d, step = np.abs(got[name] - a), 2e-4
+        assert d.mean() <= (0.02 if dtype == "fp32" else 0.05) * step, name
+        assert np.quantile(d, 0.99) <= 0.5 * step and d.max() <= 2.01 * step, name
+    # the inference path runs on the re-packed weights: same output as the oracle with the updated weights
+    lr_t, lr_tm1, est, _ = step_data(300, B, h, w)
+    out, lw = ctx.step(lr_t, lr_tm1, est)
+    want_out, want_lw = rt.generator_step(got, lr_t, lr_tm1, est)
+    assert np.abs(out - want_out).max() <= 1e-3
+    assert np.abs(lw - want_lw).max() <= 1e-3
+    # load_weights after training replaces the master weights too
+    ctx.load_weights(weights7)
+    out0, _ = ctx.step(lr_t, lr_tm1, est)
+    want0, _ = rt.generator_step(weights7, lr_t, lr_tm1, est)
+    assert np.abs(out0 - want0).max() <= 1e-3
+    _, flat = ctx.train_grads(*step_data(200, B, h, w), read=True)
+    _, want_g, _ = ref_train.loss_and_grads(weights7, *step_data(200, B, h, w))
+    check_grads(ctx, flat, want_g, 2e-3 if dtype == "fp32" else 5e-3)
+    ctx.close()
+
+
+def test_training_is_refused_where_it_cannot_run(sh, weights7):
+    ctx = sh.Context(16, 16, max_batch=1, dtype="bf16")
+    ctx.load_weights(weights7)
+    with pytest.raises(ValueError):
+        ctx.train_grads(*step_data(1, 1, 16, 16))
+    ctx.close()
+    ctx = sh.Context(16, 16, max_batch=1, dtype="fp32", model="tecogan")
+    ctx.load_weights(weights7)
+    with pytest.raises(ValueError):
+        ctx.train_grads(*step_data(1, 1, 16, 16))
+    ctx.close()
+    ctx = sh.Context(16, 16, max_batch=1, dtype="fp32")
+    with pytest.raises(ValueError):                       # weights not loaded
+        ctx.train_grads(*step_data(1, 1, 16, 16))
+    ctx.load_weights(weights7)
+    with pytest.raises(ValueError):                       # batch > max_batch
+        ctx.train_grads(*step_data(1, 2, 16, 16))
+    ctx.close()
