@@ -1,7 +1,7 @@
 """Frame-Recurrent Video Super-Resolution on MI355X: drop-in for reference FRVSR.py.
 
 Same class, constructor and stage methods as the reference (FRVSR.py:19-26, build :27,
-train :76, eval :205, run :379); the generator graph of FRVSR.py:55-66 is one native
+train :76 (native training step, see train / make_train_batch), eval :205, run :379); the generator graph of FRVSR.py:55-66 is one native
 context (libsr_hip.so), reachable through the same attributes:
 ``frvsr, fnet, srnet, upscaling, hr_warp, lr_warp, space2depth``.
 
@@ -17,9 +17,12 @@ import os
 
 import numpy as np
 
-from layers import (FNet, GeneratorCore, GeneratorModel, Space2Depth, SRNet, Upscaling, Warp)
-from utils import (blur_cubic_downscale, box_downscale, cubic_upscale4, denormalize, get_videos, load_clip, merge_tiles, normalize, psnr,
-                   shard_range, split_tiles, ssim)
+import yaml
+
+import dp
+from layers import (Adam, FNet, GeneratorCore, GeneratorModel, Space2Depth, SRNet, Upscaling, Warp)
+from utils import (blur_cubic_downscale, box_downscale, cubic_upscale4, denormalize, get_frames, get_videos, load_clip,
+                   merge_tiles, normalize, psnr, shard_range, split_tiles, ssim)
 
 
 class FrameRecurrentVideoSR(object):
@@ -52,6 +55,9 @@ class FrameRecurrentVideoSR(object):
         self.lr_warp = Warp(self.lr_shape, 2).build()
         self.space2depth = Space2Depth(self.hr_shape).build()
         self.frvsr = GeneratorModel(self.core, 'FRVSR')
+        # loss functions and learning rate of the reference (FRVSR.py:69-71)
+        self.opt = Adam(lr=1e-4)
+        self.frvsr.compile(loss=['mean_squared_error', 'mean_squared_error'], loss_weights=[1., 1.], optimizer=self.opt)
         print('[INFO] Frame-Recurrent Video Super Resolution ready.')
 
     # the model object holding the generator ('frvsr' here, 'generator' in TecoGAN)
@@ -65,10 +71,92 @@ class FrameRecurrentVideoSR(object):
             print('[INFO] Loading pretrained model ...')
             self._generator().load_weights(path)
 
+    # ------------------------------------------------------------------ training
+    def make_train_batch(self, hr_batch):
+        """hr_batch [B_clips, c, H, W, 3] float32 in [0,1] -> ([lr, prev_lr, prev_est], [hr, lr]) with
+        B_clips*c samples in the reference's order b = clip*c + frame (FRVSR.py:115-155): LR = blur + cubic
+        downscale, previous LR frame (zeros at frame 0), previous estimate = the generator's own output for
+        the previous frame, computed WITHOUT gradient (zeros at frame 0).  The reference computes those
+        estimates one predict per sample and, from frame 2 on, feeds predict the estimate of frame b-3
+        (``prev_est_batch[b-2]``, FRVSR.py:149); here the clips advance in lock step through the
+        device-resident recurrence, est_f = G(lr_f, lr_f-1, est_f-1) (SURVEY.md Appendix B decision)."""
+        n, c = hr_batch.shape[:2]
+        lr = np.stack([blur_cubic_downscale(clip) for clip in hr_batch])          # [n, c, h, w, 3]
+        gen = self._generator()
+        prev_est = np.zeros((n, c) + self.hr_shape, np.float32)
+        gen.clip_begin(n)
+        for f in range(c - 1):
+            prev_est[:, f + 1] = gen.clip_push(lr[:, f])
+        prev_lr = np.zeros_like(lr)
+        prev_lr[:, 1:] = lr[:, :-1]
+        flat = lambda a: np.ascontiguousarray(a.reshape((n * c,) + a.shape[2:]))
+        lr_b = flat(lr)
+        return [lr_b, flat(prev_lr), flat(prev_est)], [flat(hr_batch), lr_b]
+
     def train(self):
-        raise NotImplementedError(
-            'training (reference FRVSR.py:76-202) is not part of this round: backward kernels and the '
-            'RCCL gradient all-reduce are the next rows of the scope table (SURVEY.md section 8 f)')
+        """Reference FRVSR.py:76-202.  One process per GPU: every rank draws its own ``batch_size`` clips, the
+        gradient is averaged over the ranks (layers.GeneratorModel.train_on_batch), rank 0 writes samples
+        and checkpoints.  Samples are .npy arrays (LR-bicubic | estimate | HR side by side rows as in the
+        reference's JPG, no OpenCV here)."""
+        cfg = self.configs['train']
+        rank, world, _ = dp.world()
+        i = 0
+        samples_dir = os.path.join(self.output_dir, 'Samples')
+        checkpoints_dir = os.path.join(self.output_dir, 'Checkpoints')
+        if rank == 0:
+            os.makedirs(samples_dir, exist_ok=True)
+            os.makedirs(checkpoints_dir, exist_ok=True)
+        videos = get_videos(self.configs)
+        if not videos:
+            raise ValueError('no training clips found in data.videos')
+        gen = self._generator()
+        pre = self.configs['cnn'].get('pretrained_model')
+        if pre:
+            self._load_pretrained()
+            try:
+                i = int(os.path.splitext(pre)[0].split('_')[-1])
+            except ValueError:
+                print('[Info] Not valid initial iteration. Setting initial iteration to 0.')
+                i = 0
+            print('[INFO] Model ready.')
+        if world > 1:
+            dp.init_if_needed()
+            self.core.set_tensors(dp.broadcast_weights_(self.core.tensors, self.core.device))
+        rng = np.random.RandomState(None if cfg.get('seed') is None else int(cfg['seed']) + rank)   # train.seed: optional, reproducible runs
+        clips = {}
+        print('[INFO] Starting training process...')
+        loss = None
+        while i < cfg['iterations'] + 1:
+            picks = rng.randint(0, len(videos), size=cfg['batch_size'])
+            hr = []
+            for j in picks:
+                if j not in clips:
+                    clips[j] = load_clip(videos[j])
+                frames = get_frames(clips[j], self.configs, rng)
+                hr.append(normalize(frames) if frames.dtype == np.uint8 else frames.astype(np.float32))
+            net_input, net_output = self.make_train_batch(np.stack(hr))
+            loss = gen.train_on_batch(net_input, net_output)
+            if rank == 0 and i % cfg['info_freq'] == 0:
+                print('[INFO]', '-' * 15, 'Iteration %d' % i, '-' * 15)
+                print('[INFO] Total loss: %f \t SR loss: %f \t Flow loss: %f' % (loss[0], loss[1], loss[2]))
+            if rank == 0 and i % cfg['sample_freq'] == 0:
+                est, _ = gen.predict([a[0:1] for a in net_input])
+                hr0, lr0 = net_output[0][0], net_input[0][0]
+                bic = cubic_upscale4(lr0[None])[0]
+                print('[INFO] FRVSR PSNR: %f \t Bicubic PSNR: %f' % (psnr(est[0], hr0), psnr(bic, hr0)))
+                window = np.concatenate([denormalize(np.clip(bic, 0, 1)), denormalize(est[0]), denormalize(hr0)], axis=0)
+                np.save(os.path.join(samples_dir, 'Sample_%d.npy' % i), window)
+            if rank == 0 and i % cfg['checkpoint_freq'] == 0:
+                print('[INFO] Saving model...')
+                path = os.path.join(checkpoints_dir, 'frvsr_model_weights_%d.h5' % i)
+                gen.save_weights(path)
+                print('[INFO] Model saved.')
+                self.configs['cnn']['pretrained_model'] = path
+                with open(os.path.join(self.output_dir, 'FRVSR.yaml'), 'w') as fh:
+                    yaml.dump(self.configs, fh, default_flow_style=False)
+            i += 1
+        print('[INFO] Training process ready.')
+        return loss
 
     def run(self):
         raise NotImplementedError('the webcam / video demo UI (reference FRVSR.py:379-536) is out of scope')

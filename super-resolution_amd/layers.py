@@ -73,6 +73,7 @@ class GeneratorCore:
         self.tensors = glorot_init(seed)      # [(keras_name, array)] in file order
         self._ctx = None
         self._ctx_batch = 0
+        self._dirty = False                   # the ctx holds newer weights than self.tensors (after training)
 
     # -- weights ---------------------------------------------------------------
     def set_tensors(self, tensors):
@@ -89,10 +90,18 @@ class GeneratorCore:
             grp = wname.split("/")[0]
             new.append((name if name.startswith(grp + "/") else wname, arr))
         self.tensors = new
+        self._dirty = False
         if self._ctx is not None:
             self._ctx.load_weights(self.tensors)
 
+    def refresh(self):
+        """After train_on_batch the master weights live on the device: pull them before anyone reads."""
+        if self._dirty and self._ctx is not None:
+            self.tensors = self._ctx.get_weights()
+        self._dirty = False
+
     def group(self, prefix):
+        self.refresh()
         return [(n, a) for n, a in self.tensors if n.startswith(prefix + "/")]
 
     def set_group(self, prefix, arrays):
@@ -107,6 +116,10 @@ class GeneratorCore:
     def ctx(self, batch):
         if self._ctx is None or batch > self._ctx_batch:
             if self._ctx is not None:
+                if self._ctx.train_iterations():
+                    print('[WARN] the batch grew after training started: the native context is rebuilt, '
+                          'weights are kept, Adam moments restart from zero')
+                self.refresh()
                 self._ctx.close()
             h, w, _ = self.lr_shape
             self._ctx = sr_hip.Context(h, w, max_batch=int(batch), dtype=self.dtype, model=self.model,
@@ -277,6 +290,17 @@ class Warp(object):
         return WarpModel(self.idx)
 
 
+class Adam(object):
+    """keras.optimizers.Adam as the reference constructs it (FRVSR.py:69: ``Adam(lr=1e-4)``); Keras 2.2.4
+    defaults for the rest.  The update itself runs on the device (sr_train_apply)."""
+
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=None, decay=0., amsgrad=False):
+        if decay or amsgrad:
+            raise NotImplementedError('Adam decay / amsgrad are not used by the reference and not built')
+        self.lr, self.beta_1, self.beta_2 = float(lr), float(beta_1), float(beta_2)
+        self.epsilon = 1e-7 if epsilon is None else float(epsilon)      # K.epsilon()
+
+
 class GeneratorModel(_CoreModel):
     """frvsr / generator: [I_LR_t, I_LR_t_1, I_est_t_1] -> [I_est_t, I_LR_est_t_1]
     (reference FRVSR.py:65-66, TecoGAN.py:78-79).  Inputs may be float64 (np.zeros default,
@@ -290,6 +314,46 @@ class GeneratorModel(_CoreModel):
         lr_t, lr_tm1, est_tm1 = _as_list(x)
         est, lr_warp = self.core.ctx(len(lr_t)).step(lr_t, lr_tm1, est_tm1, want_lr_warp=True)
         return [est, lr_warp]
+
+    # -- training (reference FRVSR.py:69-71,156)
+    optimizer = None
+
+    def compile(self, loss, loss_weights=None, optimizer=None):
+        """Only what the reference compiles (FRVSR.py:70-71): two mean-squared-error outputs weighted 1, 1."""
+        losses = list(loss) if isinstance(loss, (list, tuple)) else [loss]
+        weights = [1., 1.] if loss_weights is None else [float(v) for v in loss_weights]
+        if losses != ['mean_squared_error'] * 2 or weights != [1., 1.]:
+            raise NotImplementedError("the native training step implements loss=['mean_squared_error'] * 2 with "
+                                      "loss_weights=[1., 1.] (reference FRVSR.py:70-71)")
+        self.optimizer = optimizer if optimizer is not None else Adam()
+
+    def train_on_batch(self, x, y):
+        """[I_LR_t, I_LR_t_1, I_est_t_1], [I_HR_t, I_LR_t] -> [total, sr_loss, flow_loss] like Keras
+        (FRVSR.py:154-156).  The flow loss compares the warped previous LR frame with I_LR_t itself, which
+        is what the reference passes as the second target; any other target is refused.  Under
+        torch.distributed (one process per GPU) the flat gradient is averaged over the ranks with one
+        RCCL all-reduce before the Adam step, i.e. the job trains on the union of the ranks' batches."""
+        if self.optimizer is None:
+            raise RuntimeError('You must compile a model before training/testing. Use `model.compile(optimizer, loss)`.')
+        lr_t, lr_tm1, est_tm1 = _as_list(x)
+        hr_t, flow_target = _as_list(y)
+        if flow_target is not lr_t and not np.array_equal(np.asarray(flow_target, np.float32), np.asarray(lr_t, np.float32)):
+            raise NotImplementedError('the second target must be I_LR_t (reference FRVSR.py:155)')
+        ctx = self.core.ctx(len(lr_t))
+        opt = self.optimizer
+        import dp
+        if dp.world()[1] > 1:
+            dp.init_if_needed()
+            if getattr(self, '_gbuf', None) is None:
+                self._gbuf = dp.GradBuffer(ctx.param_count(), self.core.device)
+            losses = ctx.train_grads(lr_t, lr_tm1, est_tm1, hr_t, d_grads=self._gbuf.ptr())
+            losses = self._gbuf.reduce(losses)
+            ctx.train_apply(d_grads=self._gbuf.ptr(), lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon)
+        else:
+            losses = ctx.train_grads(lr_t, lr_tm1, est_tm1, hr_t)
+            ctx.train_apply(lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon)
+        self.core._dirty = True
+        return losses
 
     # device-resident recurrence (state never leaves the GPU); used by the eval drivers
     def clip_begin(self, batch):

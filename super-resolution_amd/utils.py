@@ -37,6 +37,25 @@ def load_clip(path):
     return clip
 
 
+def get_frames(video, configs, rng=np.random):
+    """c consecutive HR frames of a clip (reference utils.py:34-54), from a .npy clip instead of
+    cv2.VideoCapture: a random start frame with ``train.c_frames`` frames after it.  The reference
+    squeezes every frame to high_res x high_res with an arbitrary-ratio cv2 cubic resize; without OpenCV a
+    random high_res crop (one position for the whole sequence) is taken instead -- frames must be at least
+    that large.  Returns [c, high_res, high_res_w, 3] in the clip's dtype."""
+    clip = load_clip(video) if isinstance(video, str) else video
+    c = int(configs['train']['c_frames'])
+    hh = int(configs['data']['high_res'])
+    ww = int(configs['data'].get('high_res_w', hh))
+    T, H, W, _ = clip.shape
+    if T < c or H < hh or W < ww:
+        raise ValueError(f'clip of shape {clip.shape} is too small for {c} frames of {hh}x{ww}')
+    t0 = int(rng.randint(0, T - c + 1))
+    y0 = int(rng.randint(0, H - hh + 1))
+    x0 = int(rng.randint(0, W - ww + 1))
+    return clip[t0:t0 + c, y0:y0 + hh, x0:x0 + ww]
+
+
 def normalize(input_data):
     return input_data.astype(np.float32) / 255.0
 

@@ -80,3 +80,48 @@ def test_eval_driver_tiles_state_and_metrics(tmp_path, weights7):
     assert np.abs(got - np.floor(want[:, 0] * 255.0)).max() <= 1.0      # uint8 truncation of values within 1e-3
     frames_psnr = [utils.psnr(hr_n[t], est[t].astype(np.float32) / 255.0) for t in (0, 10)]
     assert abs(mean_psnr - np.mean(frames_psnr)) < 0.05
+
+
+def test_train_stage_runs_the_reference_loop(tmp_path, weights7):
+    """stage.train through the facade (reference FRVSR.py:76-202): batches of batch_size clips x c_frames
+    frames, previous estimates from the generator itself, train_on_batch, checkpoints that load back.  The
+    first batch is checked against the oracle's train_on_batch; training then lowers the loss on a fixed clip."""
+    from oracle import ref_train
+    import utils
+    import weights_io
+    m = build('frvsr', (16, 16, 3), tmp_path, weights7)
+    os.makedirs(tmp_path / 'clips')
+    for k in range(2):
+        np.save(tmp_path / 'clips' / f'{k}.npy', (rn.synth_clip(20 + k, 8, 96, 96, scale=4) * 255).astype(np.uint8))
+    m.configs['train'] = {'iterations': 0, 'batch_size': 2, 'c_frames': 3, 'sample_freq': 1, 'checkpoint_freq': 1,
+                          'info_freq': 1, 'seed': 1}
+    m.configs['data'].update(high_res=64)
+    # one batch by hand: the facade's inputs are what the oracle's generator produces for the same clips
+    hr = np.stack([utils.normalize(utils.get_frames(str(tmp_path / 'clips' / f'{k}.npy'), m.configs, np.random.RandomState(k)))
+                   for k in range(2)])
+    m._load_pretrained()
+    x, y = m.make_train_batch(hr)
+    assert [a.shape for a in x] == [(6, 16, 16, 3), (6, 16, 16, 3), (6, 64, 64, 3)] and y[1] is x[0]
+    lr = utils.blur_cubic_downscale(hr[1])
+    want = rt.run_clip(weights7, lr[:, None])                                 # clip 1 through the oracle
+    assert not x[1][3].any() and not x[2][3].any()                           # frame 0: zero state (FRVSR.py:124-125)
+    assert np.array_equal(x[1][4], lr[0]) and np.abs(x[2][5] - want[1, 0]).max() <= 1e-3
+    new_w, want_l = ref_train.train_on_batch(dict(weights7), ref_train.KerasAdam(1e-4), x[0], x[1], x[2], y[0])
+    loss = m.frvsr.train_on_batch(x, y)
+    assert np.allclose(loss, want_l, rtol=1e-4)
+    got = dict(zip(weights7.keys(), m.frvsr.get_weights()))                  # get_weights sees the trained values
+    d = np.concatenate([np.abs(got[n] - new_w[n]).ravel() for n in new_w])
+    assert d.mean() <= 0.02 * 1e-4 and np.abs(got['SRNet/conv2d_36/bias:0'] - weights7['SRNet/conv2d_36/bias:0']).max() > 5e-5
+    first = loss[0]
+    # the stage itself: 1 iteration (i = 0), checkpoint + sample + yaml written (rank 0)
+    m.train()
+    ck = tmp_path / 'Checkpoints' / 'frvsr_model_weights_0.h5'
+    assert ck.exists() and (tmp_path / 'Samples' / 'Sample_0.npy').exists() and (tmp_path / 'FRVSR.yaml').exists()
+    assert np.load(tmp_path / 'Samples' / 'Sample_0.npy').shape == (192, 64, 3)
+    saved = weights_io.read_tensors(str(ck))
+    for (n, a), b in zip(saved, m.frvsr.get_weights()):
+        np.testing.assert_array_equal(a, b)
+    # 40 more steps on the same batch: the loss goes down (Adam at 1e-4 on 6 samples)
+    for _ in range(40):
+        loss = m.frvsr.train_on_batch(x, y)
+    assert loss[0] < 0.9 * first

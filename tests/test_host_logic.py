@@ -251,11 +251,12 @@ def test_yaml_surface(tmp_path):
 
 
 def test_out_of_scope_stages_say_so():
+    from TecoGAN import TecoGAN
     m = FrameRecurrentVideoSR((16, 16, 3), (64, 64, 3), '/tmp/o', CFG)
     with pytest.raises(NotImplementedError):
-        m.train()
-    with pytest.raises(NotImplementedError):
         m.run()
+    with pytest.raises(NotImplementedError):
+        TecoGAN((16, 16, 3), (64, 64, 3), '/tmp/o', CFG).train()     # adversarial training: a later row
 
 
 def test_clip_loader_rejects_videos(tmp_path):
@@ -265,3 +266,73 @@ def test_clip_loader_rejects_videos(tmp_path):
     np.save(tmp_path / 'c.npy', np.zeros((2, 8, 8, 3), np.uint8))
     assert utils.load_clip(str(tmp_path / 'c.npy')).shape == (2, 8, 8, 3)
     assert utils.get_videos({'data': {'videos': str(tmp_path)}}) == [str(tmp_path / 'a.mp4'), str(tmp_path / 'c.npy')]
+
+
+# ------------------------------------------------------------------ training, host side
+def test_keras_adam_restatement_first_steps():
+    """Keras 2.2.4 Adam: the first update is lr * g / (|g| + eps * sqrt(1 - beta_2)) ~ lr * sign(g); with a
+    constant gradient every later update is lr as well (bias corrections cancel)."""
+    from oracle import ref_train
+    opt = ref_train.KerasAdam(lr=1e-3)
+    p = {"w": np.array([1.0, -2.0, 0.5], np.float32)}
+    g = {"w": np.array([0.3, -4.0, 1e-3], np.float64)}
+    p1 = opt.step(p, g)
+    assert np.allclose(p["w"] - p1["w"], 1e-3 * np.sign(g["w"]), rtol=5e-3)     # epsilon shows at |g| = 1e-3: 0.3 %
+    assert np.allclose((p["w"] - p1["w"])[:2], 1e-3 * np.sign(g["w"])[:2], rtol=1e-4)
+    p2 = opt.step(p1, g)
+    assert np.allclose(p1["w"] - p2["w"], 1e-3 * np.sign(g["w"]), rtol=5e-3)
+    # hand-evaluated second step with a changed gradient: m = .9*.1*g1 + .1*g2, v = .999*.001*g1^2 + .001*g2^2
+    opt = ref_train.KerasAdam(lr=1e-3)
+    q = opt.step({"w": np.zeros(1, np.float32)}, {"w": np.array([1.0])})
+    q = opt.step(q, {"w": np.array([-1.0])})
+    m, v = 0.9 * 0.1 - 0.1, 0.999 * 0.001 + 0.001
+    lr_t = 1e-3 * np.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
+    assert np.allclose(q["w"], -1e-3 - lr_t * m / (np.sqrt(v) + 1e-7), rtol=1e-5)
+
+
+def test_oracle_loss_is_the_keras_mean_over_all_elements():
+    from oracle import ref_train
+    from oracle import ref_torch as rt
+    w = rn.make_weights(seed=7)
+    rng = np.random.default_rng(3)
+    a, b = rng.random((2, 8, 8, 3), dtype=np.float32), rng.random((2, 8, 8, 3), dtype=np.float32)
+    c, hr = rng.random((2, 32, 32, 3), dtype=np.float32), rng.random((2, 32, 32, 3), dtype=np.float32)
+    losses, grads, (est, lw) = ref_train.loss_and_grads(w, a, b, c, hr)
+    assert abs(losses[1] - np.mean((est - hr.astype(np.float64)) ** 2)) < 1e-12
+    assert abs(losses[2] - np.mean((lw - a.astype(np.float64)) ** 2)) < 1e-12
+    assert abs(losses[0] - losses[1] - losses[2]) < 1e-15
+    assert list(grads) == list(w) and all(grads[n].shape == w[n].shape for n in w)
+    # finite-difference check of one weight through both losses (FNet's first bias feeds both warps)
+    n = "FNet/conv2d_1/bias:0"
+    eps = 1e-6
+    wp, wm = dict(w), dict(w)
+    wp[n] = w[n].astype(np.float64); wp[n][3] += eps
+    wm[n] = w[n].astype(np.float64); wm[n][3] -= eps
+    lp = ref_train.loss_and_grads(wp, a, b, c, hr)[0][0]
+    lm = ref_train.loss_and_grads(wm, a, b, c, hr)[0][0]
+    assert abs((lp - lm) / (2 * eps) - grads[n][3]) <= 1e-6 * max(1.0, abs(grads[n][3]) * 1e3)
+
+
+def test_get_frames_and_compile_surface(tmp_path):
+    import utils
+    from layers import Adam, GeneratorCore, GeneratorModel
+    clip = (np.arange(9 * 40 * 48 * 3) % 251).astype(np.uint8).reshape(9, 40, 48, 3)
+    cfg = {"train": {"c_frames": 4}, "data": {"high_res": 32}}
+    fr = utils.get_frames(clip, cfg, np.random.RandomState(0))
+    assert fr.shape == (4, 32, 32, 3)
+    found = [(t, y, x) for t in range(6) for y in range(9) for x in range(17)
+             if np.array_equal(fr, clip[t:t + 4, y:y + 32, x:x + 32])]
+    assert len(found) >= 1                                   # 4 consecutive frames, one crop position for all
+    with pytest.raises(ValueError):
+        utils.get_frames(clip[:3], cfg)
+    m = GeneratorModel(GeneratorCore((16, 16, 3)), "FRVSR")
+    with pytest.raises(RuntimeError):
+        m.train_on_batch([np.zeros((1, 16, 16, 3))] * 2 + [np.zeros((1, 64, 64, 3))], [np.zeros((1, 64, 64, 3)), np.zeros((1, 16, 16, 3))])
+    with pytest.raises(NotImplementedError):
+        m.compile(loss=["mean_squared_error", "mean_absolute_error"], optimizer=Adam(1e-4))
+    with pytest.raises(NotImplementedError):
+        m.compile(loss=["mean_squared_error"] * 2, loss_weights=[1., 0.5], optimizer=Adam(1e-4))
+    m.compile(loss=["mean_squared_error"] * 2, loss_weights=[1., 1.], optimizer=Adam(lr=1e-4))
+    assert m.optimizer.lr == 1e-4 and m.optimizer.epsilon == 1e-7
+    with pytest.raises(NotImplementedError):                 # second target must be I_LR_t
+        m.train_on_batch([np.zeros((1, 16, 16, 3))] * 2 + [np.zeros((1, 64, 64, 3))], [np.zeros((1, 64, 64, 3)), np.ones((1, 16, 16, 3))])
