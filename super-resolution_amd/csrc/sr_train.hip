@@ -172,7 +172,9 @@ struct Tape {
         wa.ycs = ycs;
         wa.convt = mode == M_CONVT;
         const double px = (double)B * H * W;
-        ProfScope ps(c, mode == M_CONVT ? "train.wgradT" : "train.wgrad", px * 18.0 * cin * cout, px * 4.0 * (cin + (mode == M_CONVT ? 4 : 1) * cout));
+        char nm[48];
+        snprintf(nm, sizeof nm, "train.wgrad%s %d>%d @%dx%d", mode == M_CONVT ? "T" : "", cin, cout, H, W);
+        ProfScope ps(c, nm, px * 18.0 * cin * cout, px * 4.0 * (cin + (mode == M_CONVT ? 4 : 1) * cout));
         LAUNCHCHK(c, "wgrad", launch_wgrad(wa, st));
         return SR_OK;
     }

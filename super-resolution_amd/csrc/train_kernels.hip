@@ -26,23 +26,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 static inline int blocks_for(long n, int bs) { return (int)((n + bs - 1) / bs); }
 
 // ================================================================== wgrad
-constexpr int WG_PART = 9 * 1024 + 64;   // floats of one (slice, block) partial: 9 taps x 32 x 32 + bias lanes
+// modes: 0 Conv2D, 1 Conv2DTranspose s2, 2 Conv2D with <= 3 output channels (SRNet's last layer, FNet's
+// flow head): the 9 taps are folded into the GEMM's N dimension (column j = tap*cout + co reads dY at the
+// pixel shifted AGAINST the tap), one MFMA per k-step instead of nine with 29 of 32 columns empty.
+enum { WG_CONV = 0, WG_CONVT = 1, WG_TAPSN = 2 };
 
 struct WgradPlan {
+    int mode;
     int R, S;            // rows / columns of one tap's matrix: conv (cin, cout), transposed conv (cout, cin)
-    int nrb, ncolb, nblk, nbg, nslices;
+    int nrb, ncolb, nblk, nslices;
+    int part;            // floats of one (slice, block) partial: ntap x 32 x 32 accumulators + 64 bias lanes
 };
 
 static WgradPlan wgrad_plan(int B, int H, int W, int cin, int cout, int convt) {
     WgradPlan p;
+    p.mode = convt ? WG_CONVT : (cout <= 3 ? WG_TAPSN : WG_CONV);
     p.R = convt ? cout : cin;
     p.S = convt ? cin : cout;
     p.nrb = (p.R + 31) / 32;
-    p.ncolb = (p.S + 31) / 32;
+    p.ncolb = p.mode == WG_TAPSN ? 1 : (p.S + 31) / 32;
     p.nblk = p.nrb * p.ncolb;
-    p.nbg = (p.nblk + 3) / 4;
+    p.part = (p.mode == WG_TAPSN ? 1 : 9) * 1024 + 64;
     const long pairs = ((long)B * H * W + 1) / 2;
-    long ns = 1024 / p.nbg;                       // ~4 workgroups per CU
+    // two waves per SIMD of 144 accumulator registers fill the chip with 2048 waves; the light taps-in-N
+    // waves run eight deep
+    long ns = (p.mode == WG_TAPSN ? 8192 : 2048) / p.nblk;
     if (ns > pairs / 16) ns = pairs / 16;         // at least 16 MFMA k-steps per slice
     if (ns < 1) ns = 1;
     p.nslices = (int)ns;
@@ -51,16 +59,20 @@ static WgradPlan wgrad_plan(int B, int H, int W, int cin, int cout, int convt) {
 
 size_t wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int convt) {
     const WgradPlan p = wgrad_plan(B, H, W, cin, cout, convt);
-    return (size_t)p.nslices * p.nblk * WG_PART * sizeof(float);
+    return (size_t)p.nslices * p.nblk * p.part * sizeof(float);
 }
 
-template <int CONVT>
+// Every load is unconditional from a clamped (always valid) address and masked afterwards: a branch per
+// load would serialise them and force a full vmcnt(0) before the MFMAs; this way the next k-step's ten
+// loads are in flight while the current one multiplies.
+template <int MODE>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, const WgradPlan pl) {
+    constexpr int NT = MODE == WG_TAPSN ? 1 : 9;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, kh = lane >> 5;
-    const int blk = (blockIdx.x % pl.nbg) * 4 + wave;
-    const int slice = blockIdx.x / pl.nbg;
-    if (blk >= pl.nblk) return;   // no barrier in this kernel
+    const int gw = blockIdx.x * 4 + wave;
+    const int blk = gw % pl.nblk, slice = gw / pl.nblk;
+    if (slice >= pl.nslices) return;   // no barrier in this kernel
     const int rb = blk / pl.ncolb, cb = blk - rb * pl.ncolb;
     const int H = a.H, W = a.W;
     const unsigned npix = (unsigned)a.B * H * W;
@@ -68,91 +80,164 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, const Wgr
     const unsigned per = (pairs + pl.nslices - 1) / pl.nslices;
     const unsigned q0 = slice * per, q1 = min(q0 + per, pairs);
     // channel of this lane in the A (row) and B (column) operands
-    const int ch_a = rb * 32 + i, ch_b = cb * 32 + i;
-    const bool a_ok = ch_a < pl.R, b_ok = ch_b < pl.S;
-    f32x16 acc[9];
+    const int ch_a = rb * 32 + i;
+    const bool a_ok = ch_a < pl.R;
+    int ch_b = cb * 32 + i;
+    bool b_ok = ch_b < pl.S;
+    int btap = 4;
+    if constexpr (MODE == WG_TAPSN) {
+        btap = min(i / pl.S, 8);
+        ch_b = i - btap * pl.S;
+        b_ok = i < 9 * pl.S;
+    }
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
-    for (unsigned q = q0; q < q1; ++q) {
-        const unsigned p = 2 * q + kh;
+    // this lane's pixel cursor p = 2q + kh as (row r = b*H + y, y, x); it advances by two pixels per k-step
+    unsigned p = 2 * q0 + kh;
+    int x = p % W;
+    unsigned r = p / W;
+    int y = r % H;
+    const int srow = MODE == WG_CONVT ? 2 * W * a.ycs : W * a.xcs, scol = MODE == WG_CONVT ? a.ycs : a.xcs;
+    const float* pa = (MODE == WG_CONVT ? a.dy : a.x) + (a_ok ? ch_a : 0);
+    const float* pb = (MODE == WG_CONVT ? a.x : a.dy) + (b_ok ? ch_b : 0);
+    const int bcs = MODE == WG_CONVT ? a.xcs : a.ycs;
+    // taps-in-N: column (tap, co) reads dY at pixel - (tap offset)
+    const int bdy = 1 - btap / 3, bdx = 1 - btap % 3;
+    auto fetch = [&](float (&av)[NT], float& bv) {
         const bool valid = p < npix;
-        const int x = p % W;
-        const unsigned t1 = p / W;
-        const int y = t1 % H;
-        const int b = t1 / H;
-        float av[9], bv;
-        if constexpr (!CONVT) {
-            bv = (valid && b_ok) ? a.dy[(size_t)p * a.ycs + ch_b] : 0.f;
-            bsum += bv;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                const bool in = valid && a_ok && yy >= 0 && yy < H && xx >= 0 && xx < W;
-                av[t] = in ? a.x[(((size_t)b * H + yy) * W + xx) * a.xcs + ch_a] : 0.f;
-            }
+        const size_t pc = valid ? p : 0;
+        if constexpr (MODE == WG_TAPSN) {
+            const bool in = valid && b_ok && (unsigned)(y + bdy) < (unsigned)H && (unsigned)(x + bdx) < (unsigned)W;
+            const float v = pb[(ptrdiff_t)(pc * bcs) + (in ? (bdy * W + bdx) * bcs : 0)];
+            bv = in ? v : 0.f;
+            const float u = pa[pc * a.xcs];
+            av[0] = (valid && a_ok) ? u : 0.f;
         } else {
-            bv = (valid && b_ok) ? a.x[(size_t)p * a.xcs + ch_b] : 0.f;
+            const float v = pb[pc * bcs];
+            bv = (valid && b_ok) ? v : 0.f;
+            const bool ok = valid && a_ok;
+            if constexpr (MODE == WG_CONV) {
+                const float* c = pa + pc * a.xcs;
+                const bool my[3] = {y > 0, true, y < H - 1}, mx[3] = {x > 0, true, x < W - 1};
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int yy = 2 * y + t / 3, xx = 2 * x + t % 3;
-                const bool in = valid && a_ok && yy < 2 * H && xx < 2 * W;
-                av[t] = in ? a.dy[(((size_t)b * 2 * H + yy) * 2 * W + xx) * a.ycs + ch_a] : 0.f;
+                for (int t = 0; t < 9; ++t) {
+                    const bool in = ok && my[t / 3] && mx[t % 3];
+                    const float u = c[in ? (t / 3 - 1) * srow + (t % 3 - 1) * scol : 0];
+                    av[t] = in ? u : 0.f;
+                }
+            } else {
+                // dY pixel (2y + ky, 2x + kx) of image b: rows of all images are contiguous, 2r = b*2H + 2y
+                const float* c = pa + (valid ? ((size_t)r * 4 * W + 2 * x) * a.ycs : 0);
+                const bool my[3] = {true, true, y < H - 1}, mx[3] = {true, true, x < W - 1};
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const bool in = ok && my[t / 3] && mx[t % 3];
+                    const float u = c[in ? (t / 3) * srow + (t % 3) * scol : 0];
+                    av[t] = in ? u : 0.f;
+                }
             }
-            bsum += av[0] + av[1] + av[3] + av[4];   // the four phases cover every output pixel once
         }
+    };
+    auto advance = [&]() {
+        p += 2;
+        x += 2;
+        while (x >= W) {
+            x -= W;
+            ++r;
+            if (++y == H) y = 0;
+        }
+    };
+    float av[NT], bv = 0.f;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
+    for (int t = 0; t < NT; ++t) av[t] = 0.f;
+    if (q0 < q1) fetch(av, bv);
+    for (unsigned q = q0; q < q1; ++q) {
+        float an[NT], bn;
+        advance();
+        fetch(an, bn);   // next k-step's operands (all-masked past the end) are in flight during this one's MFMAs
+        if (q + 1 >= q1) {
+            bn = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) an[t] = 0.f;
+        }
+        // bias: conv sums dY (the centre-tap columns in taps-in-N); transposed conv: the four phases
+        // (taps 0, 1, 3, 4) cover every output pixel once
+        if constexpr (MODE == WG_CONVT) bsum += av[0] + av[1] + av[3] + av[4];
+        else bsum += bv;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) av[t] = an[t];
+        bv = bn;
     }
-    float* out = a.part + ((size_t)slice * pl.nblk + blk) * WG_PART;
+    float* out = a.part + ((size_t)slice * pl.nblk + blk) * pl.part;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 8 * (r >> 2) + 4 * kh + (r & 3);
-            out[t * 1024 + row * 32 + i] = acc[t][r];
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = 8 * (rr >> 2) + 4 * kh + (rr & 3);
+            out[t * 1024 + row * 32 + i] = acc[t][rr];
         }
-    out[9 * 1024 + lane] = bsum;
+    out[NT * 1024 + lane] = bsum;
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
-                                    const WgradPlan pl, int convt, int nbias) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// dw / db = sum of the slices' partials in slice order (deterministic).  One workgroup: 32 consecutive
+// outputs x 8 slice lanes; lane g adds slices g, g + 8, ... and the eight sums meet in LDS in lane order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           float* __restrict__ db, const WgradPlan pl, int nbias) {
+    __shared__ float red[8][32];
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + e;
     const int nw = 9 * pl.R * pl.S;
-    if (idx >= nw + nbias) return;
-    const size_t stride = (size_t)pl.nblk * WG_PART;
+    const size_t stride = (size_t)pl.nblk * pl.part;
+    const int nacc = pl.part - 64;
+    float sum = 0.f;
     if (idx < nw) {
         const int tap = idx / (pl.R * pl.S);
         const int rem = idx - tap * pl.R * pl.S;
         const int r = rem / pl.S, s = rem - r * pl.S;
-        const int blk = (r >> 5) * pl.ncolb + (s >> 5);
-        const float* p = part + (size_t)blk * WG_PART + tap * 1024 + (r & 31) * 32 + (s & 31);
-        float sum = 0.f;
-        for (int sl = 0; sl < pl.nslices; ++sl) sum += p[sl * stride];
-        dw[idx] = sum;
-    } else if (db) {
+        size_t off;
+        if (pl.mode == WG_TAPSN) off = (size_t)(r >> 5) * pl.part + (r & 31) * 32 + tap * pl.S + s;
+        else off = (size_t)((r >> 5) * pl.ncolb + (s >> 5)) * pl.part + tap * 1024 + (r & 31) * 32 + (s & 31);
+        const float* p = part + off;
+        for (int sl = g; sl < pl.nslices; sl += 8) sum += p[sl * stride];
+    } else if (idx < nw + nbias) {
         const int c = idx - nw;
-        const int blk = convt ? (c >> 5) * pl.ncolb : (c >> 5);
-        const float* p = part + (size_t)blk * WG_PART + 9 * 1024 + (c & 31);
-        float sum = 0.f;
-        for (int sl = 0; sl < pl.nslices; ++sl) sum += p[sl * stride] + p[sl * stride + 32];
-        db[c] = sum;
+        size_t off;
+        if (pl.mode == WG_TAPSN) off = nacc + 4 * pl.S + c;                          // block 0, centre-tap columns
+        else if (pl.mode == WG_CONVT) off = (size_t)((c >> 5) * pl.ncolb) * pl.part + nacc + (c & 31);
+        else off = (size_t)(c >> 5) * pl.part + nacc + (c & 31);
+        const float* p = part + off;
+        for (int sl = g; sl < pl.nslices; sl += 8) sum += p[sl * stride] + p[sl * stride + 32];
+    }
+    red[g][e] = sum;
+    __syncthreads();
+    if (g == 0) {
+        float t = red[0][e];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][e];
+        if (idx < nw) dw[idx] = t;
+        else if (idx < nw + nbias && db) db[idx - nw] = t;
     }
 }
 
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
     const WgradPlan pl = wgrad_plan(a.B, a.H, a.W, a.cin, a.cout, a.convt);
-    const dim3 grid(pl.nbg * pl.nslices), block(256);
-    if (a.convt)
-        hipLaunchKernelGGL(wgrad_kernel<1>, grid, block, 0, s, a, pl);
+    const dim3 grid((pl.nblk * pl.nslices + 3) / 4), block(256);
+    if (pl.mode == WG_CONVT)
+        hipLaunchKernelGGL(wgrad_kernel<WG_CONVT>, grid, block, 0, s, a, pl);
+    else if (pl.mode == WG_TAPSN)
+        hipLaunchKernelGGL(wgrad_kernel<WG_TAPSN>, grid, block, 0, s, a, pl);
     else
-        hipLaunchKernelGGL(wgrad_kernel<0>, grid, block, 0, s, a, pl);
+        hipLaunchKernelGGL(wgrad_kernel<WG_CONV>, grid, block, 0, s, a, pl);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int n = 9 * a.cin * a.cout + a.cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, a.part, a.dw, a.db, pl, a.convt, a.cout);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(n, 32)), dim3(256), 0, s, a.part, a.dw, a.db, pl, a.cout);
     return hipGetLastError();
 }
 
