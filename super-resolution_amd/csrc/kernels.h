@@ -93,9 +93,10 @@ struct WgradArgs {
 };
 size_t wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int convt);
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);
-// data gradient of Conv2DTranspose 3x3 s2: dy [B,2H,2W,ycs] (cout channels, a multiple of 64), w (3,3,cout,cin), dx [B,H,W,xcs]
-hipError_t launch_dgrad_s2(const float* dy, const float* w, float* dx, int B, int H, int W, int cin, int cout,
-                           int ycs, int xcs, hipStream_t s);
+// data gradient of Conv2DTranspose 3x3 s2: dy [B,2H,2W,ycs] (cout channels, a multiple of 64), w (3,3,cout,cin), dx [B,H,W,xcs];
+// relu_y (nullable, laid out like dx): the output of the ReLU that fed the layer, dx is zeroed where it is not positive
+hipError_t launch_dgrad_s2(const float* dy, const float* w, float* dx, const float* relu_y, int B, int H, int W, int cin,
+                           int cout, int ycs, int xcs, hipStream_t s);
 hipError_t launch_act_bwd(float* g, const float* y, int act, long npix, int C, int gcs, int ycs, hipStream_t s);
 hipError_t launch_maxpool2_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, hipStream_t s);
 hipError_t launch_resize_bwd(const float* gy, float* gx, int B, int H, int W, int C, int sc, int ocs, int accumulate, hipStream_t s);

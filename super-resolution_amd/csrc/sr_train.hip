@@ -261,14 +261,13 @@ int train_backward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const fl
     RC(t.wgrad(so + 44, M_CONVT, 64, 64, t.a("up1"), 64, cur, 64, 2 * H, 2 * W));
     {
         ProfScope ps(c, "train.dgrad_s2", 4.0 * L0 * 18 * 64 * 64, 4.0 * L0 * 4 * (4 * 64 + 64));
-        LAUNCHCHK(c, "dgrad_s2", launch_dgrad_s2(cur, T->d_params + T->off[so + 44], oth, B, 2 * H, 2 * W, 64, 64, 64, 64, st));
+        LAUNCHCHK(c, "dgrad_s2", launch_dgrad_s2(cur, T->d_params + T->off[so + 44], oth, t.a("up1"), B, 2 * H, 2 * W, 64, 64, 64, 64, st));
     }
-    swap();
-    RC(t.mask(cur, t.a("up1"), A_RELU, 4 * L0, 64, 64, 64));
+    swap();   // ReLU mask of up1 applied in the kernel's store
     RC(t.wgrad(so + 42, M_CONVT, 64, 64, t.a("x10_"), 64, cur, 64, H, W));
     {
         ProfScope ps(c, "train.dgrad_s2", 1.0 * L0 * 18 * 64 * 64, 1.0 * L0 * 4 * (4 * 64 + 64));
-        LAUNCHCHK(c, "dgrad_s2", launch_dgrad_s2(cur, T->d_params + T->off[so + 42], oth, B, H, W, 64, 64, 64, 64, st));
+        LAUNCHCHK(c, "dgrad_s2", launch_dgrad_s2(cur, T->d_params + T->off[so + 42], oth, nullptr, B, H, W, 64, 64, 64, 64, st));
     }
     swap();   // cur = g_x
     char xn[16], yn[16];
@@ -555,7 +554,8 @@ int conv_bwd_op(int device, int dtype, int convt, int B, int H, int W, int Cin, 
     if (!x || !w || !dy || !dw) return fail(nullptr, SR_ERR_ARG, "NULL tensor pointer");
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return fail(nullptr, SR_ERR_ARG, "non-positive dimension");
     if (dtype != SR_FP32 && dtype != SR_BF16X3) return fail(nullptr, SR_ERR_ARG, "backward ops need dtype fp32 or bf16x3");
-    if (convt && dx && Cout % 64) return fail(nullptr, SR_ERR_ARG, "transposed-conv data gradient needs Cout to be a multiple of 64");
+    if (convt && dx && (Cout % 64 || Cin % 32 || (Cin > 32 && Cin % 64)))
+        return fail(nullptr, SR_ERR_ARG, "transposed-conv data gradient needs Cout %% 64 == 0 and Cin 32 or a multiple of 64");
     DevBufs d;
     const size_t npix = (size_t)B * H * W, opix = convt ? 4 * npix : npix, nw = (size_t)9 * Cin * Cout;
     float* d_x = d.put(x, npix * Cin);
@@ -571,7 +571,7 @@ int conv_bwd_op(int device, int dtype, int convt, int B, int H, int W, int Cin, 
         float* d_dx = d.get(npix * Cin);
         if (!d_dx) return fail(nullptr, SR_ERR_HIP, "hipMalloc failed");
         if (convt) {
-            LAUNCHCHK(nullptr, "dgrad_s2", launch_dgrad_s2(d_dy, d_w, d_dx, B, H, W, Cin, Cout, Cout, Cin, nullptr));
+            LAUNCHCHK(nullptr, "dgrad_s2", launch_dgrad_s2(d_dy, d_w, d_dx, nullptr, B, H, W, Cin, Cout, Cout, Cin, nullptr));
         } else {
             ConvLayer D;
             plan_layer(D, dtype, M_CONV, Cout, Cin);

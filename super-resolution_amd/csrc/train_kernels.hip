@@ -247,8 +247,8 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
 // k-step s multiplies channel 32*kh + s), N = cin in blocks of NB*32 (blockIdx.y).
 template <int NB>
 __global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                       float* __restrict__ dx, int B, int H, int W, int K, int N,
-                                                       int ycs, int xcs) {
+                                                       float* __restrict__ dx, const float* __restrict__ relu_y,
+                                                       int B, int H, int W, int K, int N, int ycs, int xcs) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, kh = lane >> 5;
     const unsigned npix = (unsigned)B * H * W;
@@ -266,23 +266,27 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__
     for (int n = 0; n < NB; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    // loads are unconditional from clamped addresses and masked afterwards (no branch per load), so the
+    // compiler keeps the next tap's activations and the weight stream in flight under the MFMAs
+    const size_t img = valid ? (size_t)b * 2 * H : 0;
     for (int t = 0; t < 9; ++t) {
         const int yy = 2 * y + t / 3, xx = 2 * x + t % 3;
         const bool in = valid && yy < 2 * H && xx < 2 * W;
-        const float* src = dy + (((size_t)b * 2 * H + yy) * 2 * W + xx) * ycs + kh * 32;
+        const float* src = dy + (in ? ((img + yy) * 2 * W + xx) * ycs : 0) + kh * 32;
         for (int kc = 0; kc < K; kc += 64) {
             f32x4 av[8];
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                av[v] = in ? *reinterpret_cast<const f32x4*>(src + kc + 4 * v) : z;
+                const f32x4 u = *reinterpret_cast<const f32x4*>(src + kc + 4 * v);
+                av[v] = in ? u : z;
             }
-            const float* wr = w + ((size_t)t * K + kc + kh * 32) * N + n0 + i;
+            const float* wr = w + ((size_t)t * K + kc + kh * 32) * N + n0 + i;   // N % 32 == 0: every column exists
 #pragma unroll
             for (int s = 0; s < 32; ++s) {
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
-                    const float bv = (n0 + n * 32 + i < N) ? wr[(size_t)s * N + n * 32] : 0.f;
+                    const float bv = wr[(size_t)s * N + n * 32];
                     acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s >> 2][s & 3], bv, acc[n], 0, 0, 0);
                 }
             }
@@ -294,21 +298,27 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__
         for (int r = 0; r < 16; ++r) {
             const unsigned row = p0 + 8 * (r >> 2) + 4 * kh + (r & 3);
             const int ch = n0 + n * 32 + i;
-            if (row < npix && ch < N) dx[(size_t)row * xcs + ch] = acc[n][r];
+            if (row < npix && ch < N) {
+                float v = acc[n][r];
+                // ReLU of the layer that produced this convolution's input, folded into the store
+                if (relu_y && !(relu_y[(size_t)row * xcs + ch] > 0.f)) v = 0.f;
+                dx[(size_t)row * xcs + ch] = v;
+            }
         }
 }
 
-hipError_t launch_dgrad_s2(const float* dy, const float* w, float* dx, int B, int H, int W, int cin, int cout,
-                           int ycs, int xcs, hipStream_t s) {
-    if (cout % 64 || ycs % 4) return hipErrorInvalidValue;
+hipError_t launch_dgrad_s2(const float* dy, const float* w, float* dx, const float* relu_y, int B, int H, int W, int cin,
+                           int cout, int ycs, int xcs, hipStream_t s) {
+    if (cout % 64 || ycs % 4 || cin % 32) return hipErrorInvalidValue;
     const long npix = (long)B * H * W;
     const dim3 block(256);
     if (cin > 32) {
-        const dim3 grid(blocks_for(npix, 128), (cin + 63) / 64);
-        hipLaunchKernelGGL(dgrad_s2_kernel<2>, grid, block, 0, s, dy, w, dx, B, H, W, cout, cin, ycs, xcs);
+        if (cin % 64) return hipErrorInvalidValue;
+        const dim3 grid(blocks_for(npix, 128), cin / 64);
+        hipLaunchKernelGGL(dgrad_s2_kernel<2>, grid, block, 0, s, dy, w, dx, relu_y, B, H, W, cout, cin, ycs, xcs);
     } else {
         const dim3 grid(blocks_for(npix, 128), 1);
-        hipLaunchKernelGGL(dgrad_s2_kernel<1>, grid, block, 0, s, dy, w, dx, B, H, W, cout, cin, ycs, xcs);
+        hipLaunchKernelGGL(dgrad_s2_kernel<1>, grid, block, 0, s, dy, w, dx, relu_y, B, H, W, cout, cin, ycs, xcs);
     }
     return hipGetLastError();
 }
