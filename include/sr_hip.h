@@ -155,8 +155,9 @@ int sr_op_space_to_depth(int device, int B, int H, int W, int C, int bs, const f
  * - lr_t)^2) (Keras mean_squared_error = mean over every element), optimizer Adam(lr) with Keras
  * 2.2.4 defaults (beta_1 0.9, beta_2 0.999, epsilon 1e-7, lr_t = lr*sqrt(1-beta_2^t)/(1-beta_1^t)).
  * prev-LR and prev-estimate are constant inputs (no gradient through time, FRVSR.py:140-151); the
- * warps are differentiated with respect to the flow only.  ctx dtype must be fp32 or bf16x3, model
- * SR_FRVSR.  losses[3] = {total, sr_loss, flow_loss} (Keras train_on_batch order, FRVSR.py:161).
+ * warps are differentiated with respect to the flow only.  ctx dtype must be fp32 or bf16x3.  With
+ * model SR_TECOGAN the same call is generator.train_on_batch of TecoGAN's generator pre-training
+ * (reference TecoGAN.py:112-113,228): identical losses on tanh(SRNet + bilinear x4 (lr_t)).  losses[3] = {total, sr_loss, flow_loss} (Keras train_on_batch order, FRVSR.py:161).
  *
  * sr_train_grads: forward + backward of one batch (host pointers; _dev: device pointers); the
  *   gradient of all 76 tensors lands in one flat fp32 device vector in file order (kernel then

@@ -98,9 +98,32 @@ class FrameRecurrentVideoSR(object):
         gradient is averaged over the ranks (layers.GeneratorModel.train_on_batch), rank 0 writes samples
         and checkpoints.  Samples are .npy arrays (LR-bicubic | estimate | HR side by side rows as in the
         reference's JPG, no OpenCV here)."""
+        i = self._start_iteration('[INFO] Model ready.')
+        print('[INFO] Starting training process...')
+        loss = self._train_generator(i, self.configs['train']['iterations'] + 1, None,
+                                     'frvsr_model_weights_%d.h5', 'FRVSR.yaml', 'FRVSR')
+        print('[INFO] Training process ready.')
+        return loss
+
+    def _start_iteration(self, ready_msg):
+        """Load cnn.pretrained_model and take the start iteration from its file name (FRVSR.py:85-96)."""
+        i = 0
+        pre = self.configs['cnn'].get('pretrained_model')
+        if pre:
+            self._load_pretrained()
+            try:
+                i = int(os.path.splitext(pre)[0].split('_')[-1])
+            except ValueError:
+                print('[Info] Not valid initial iteration. Setting initial iteration to 0.')
+                i = 0
+            print(ready_msg)
+        return i
+
+    def _train_generator(self, i, end, lr_schedule, ckpt_pattern, yaml_name, label):
+        """The generator training loop shared by FRVSR.train (FRVSR.py:100-200) and TecoGAN's generator
+        pre-training (TecoGAN.py:178-275): iterations i .. end-1; lr_schedule(i) -> learning rate or None."""
         cfg = self.configs['train']
         rank, world, _ = dp.world()
-        i = 0
         samples_dir = os.path.join(self.output_dir, 'Samples')
         checkpoints_dir = os.path.join(self.output_dir, 'Checkpoints')
         if rank == 0:
@@ -110,23 +133,14 @@ class FrameRecurrentVideoSR(object):
         if not videos:
             raise ValueError('no training clips found in data.videos')
         gen = self._generator()
-        pre = self.configs['cnn'].get('pretrained_model')
-        if pre:
-            self._load_pretrained()
-            try:
-                i = int(os.path.splitext(pre)[0].split('_')[-1])
-            except ValueError:
-                print('[Info] Not valid initial iteration. Setting initial iteration to 0.')
-                i = 0
-            print('[INFO] Model ready.')
         if world > 1:
             dp.init_if_needed()
+            self.core.refresh()
             self.core.set_tensors(dp.broadcast_weights_(self.core.tensors, self.core.device))
         rng = np.random.RandomState(None if cfg.get('seed') is None else int(cfg['seed']) + rank)   # train.seed: optional, reproducible runs
         clips = {}
-        print('[INFO] Starting training process...')
         loss = None
-        while i < cfg['iterations'] + 1:
+        while i < end:
             picks = rng.randint(0, len(videos), size=cfg['batch_size'])
             hr = []
             for j in picks:
@@ -135,27 +149,29 @@ class FrameRecurrentVideoSR(object):
                 frames = get_frames(clips[j], self.configs, rng)
                 hr.append(normalize(frames) if frames.dtype == np.uint8 else frames.astype(np.float32))
             net_input, net_output = self.make_train_batch(np.stack(hr))
+            if lr_schedule is not None:
+                gen.optimizer.lr = float(lr_schedule(i))          # K.set_value(optimizer.lr, ...) in the reference
             loss = gen.train_on_batch(net_input, net_output)
             if rank == 0 and i % cfg['info_freq'] == 0:
                 print('[INFO]', '-' * 15, 'Iteration %d' % i, '-' * 15)
-                print('[INFO] Total loss: %f \t SR loss: %f \t Flow loss: %f' % (loss[0], loss[1], loss[2]))
+                print('[INFO] Total loss: %f \t SR loss: %f \t Flow loss: %f \t Learning rate: %f'
+                      % (loss[0], loss[1], loss[2], gen.optimizer.lr))
             if rank == 0 and i % cfg['sample_freq'] == 0:
                 est, _ = gen.predict([a[0:1] for a in net_input])
                 hr0, lr0 = net_output[0][0], net_input[0][0]
                 bic = cubic_upscale4(lr0[None])[0]
-                print('[INFO] FRVSR PSNR: %f \t Bicubic PSNR: %f' % (psnr(est[0], hr0), psnr(bic, hr0)))
-                window = np.concatenate([denormalize(np.clip(bic, 0, 1)), denormalize(est[0]), denormalize(hr0)], axis=0)
+                print('[INFO] %s PSNR: %f \t Bicubic PSNR: %f' % (label, psnr(est[0], hr0), psnr(bic, hr0)))
+                window = np.concatenate([denormalize(np.clip(bic, 0, 1)), denormalize(np.clip(est[0], 0, 1)), denormalize(hr0)], axis=0)
                 np.save(os.path.join(samples_dir, 'Sample_%d.npy' % i), window)
             if rank == 0 and i % cfg['checkpoint_freq'] == 0:
                 print('[INFO] Saving model...')
-                path = os.path.join(checkpoints_dir, 'frvsr_model_weights_%d.h5' % i)
+                path = os.path.join(checkpoints_dir, ckpt_pattern % i)
                 gen.save_weights(path)
                 print('[INFO] Model saved.')
                 self.configs['cnn']['pretrained_model'] = path
-                with open(os.path.join(self.output_dir, 'FRVSR.yaml'), 'w') as fh:
+                with open(os.path.join(self.output_dir, yaml_name), 'w') as fh:
                     yaml.dump(self.configs, fh, default_flow_style=False)
             i += 1
-        print('[INFO] Training process ready.')
         return loss
 
     def run(self):

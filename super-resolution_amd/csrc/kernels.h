@@ -106,7 +106,7 @@ hipError_t launch_hr_warp_bwd(const float* est_prev, const float* flow, const fl
                               int gcs, hipStream_t s);
 size_t mse_workspace_bytes(long npix, int gcs);
 hipError_t launch_mse_grad(const float* pred, const float* target, float* g, double* partial, float* loss_out, long npix, int C,
-                           int gcs, int clip01_mask, hipStream_t s);
+                           int gcs, const float* clip_src, int tanh_out, hipStream_t s);
 hipError_t launch_adam(float* p, float* m, float* v, const float* g, long n, float lr_t, float b1, float b2, float eps,
                        float gscale, hipStream_t s);
 // ents: srh::PackEnt {int32 src, uint32 dst}[n]

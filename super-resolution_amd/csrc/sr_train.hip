@@ -1,6 +1,7 @@
-// Training step of the FRVSR generator on the device: replaces frvsr.train_on_batch (reference
+// Training step of the FRVSR / TecoGAN generator on the device: replaces frvsr.train_on_batch (reference
 // FRVSR.py:156) for the model compiled at FRVSR.py:69-71 (two mean-squared-error losses with weights
-// 1, 1 and Adam(lr=1e-4)).  Forward with every activation kept, backward in reverse graph order,
+// 1, 1 and Adam(lr=1e-4)) and generator.train_on_batch of TecoGAN's generator pre-training
+// (TecoGAN.py:112-113,228: the same two losses on the generator with the tanh epilogue).  Forward with every activation kept, backward in reverse graph order,
 // gradients into one flat fp32 vector in the Keras file order (the buffer a data-parallel job
 // all-reduces), Adam on the flat master weights, device re-pack of the MFMA weight buffers.
 //
@@ -42,7 +43,7 @@ void layer_dims(bool is_f, int i, int& cin, int& cout, int& mode) {
 
 int talloc(sr_ctx* c, const char* name, size_t floats) {
     float* p = nullptr;
-    HIPCHK(c, hipMalloc((void**)&p, floats * sizeof(float)));
+    HIPCHK(c, hipMalloc((void**)&p, (floats ? floats : 4) * sizeof(float)));
     c->train->act[name] = p;
     return SR_OK;
 }
@@ -67,8 +68,6 @@ int train_init(sr_ctx* c) {
     if (c->train) return SR_OK;
     if (c->prec == P_BF16)
         return fail(c, SR_ERR_ARG, "training needs fp32 activations: create the ctx with dtype fp32 or bf16x3");
-    if (c->model != SR_FRVSR)
-        return fail(c, SR_ERR_ARG, "training covers the FRVSR model (reference FRVSR.py:69-71); the TecoGAN losses are not built");
     sr_train_state* T = new sr_train_state();
     c->train = T;
     for (int i = 0; i < 76; ++i) T->off[i + 1] = T->off[i] + (int64_t)c->tensors[i].data.size();
@@ -126,7 +125,8 @@ int train_init(sr_ctx* c) {
         {"u2", L2 * 256}, {"d2a", L2 * 128}, {"d2b", L2 * 128}, {"u1", L1 * 128}, {"d1a", L1 * 64}, {"d1b", L1 * 64},
         {"u0", L0 * 64}, {"c13", L0 * 32}, {"s_in", L0 * 64}, {"up1", L0 * 4 * 64}, {"up2", L0 * 16 * 64},
         {"gA", L0 * 16 * 64}, {"gB", L0 * 16 * 64}, {"g_est", L0 * 16 * 16}, {"g_flow", L0 * 16}, {"g_fhr", L0 * 16 * 2},
-        {"g_lw", L0 * 3}, {"hr", L0 * 48}};
+        {"g_lw", L0 * 3}, {"hr", L0 * 48},
+        {"s_out", c->model == SR_TECOGAN ? L0 * 48 : 0}};   // SRNet's clipped output before TecoGAN's tanh epilogue
     for (auto& p : plan)
         if ((rc = talloc(c, p.n, Bz * p.elems))) return rc;
     char nm[16];
@@ -237,6 +237,14 @@ int train_forward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const flo
     }
     RC(t.conv(S[21], t.a("x10_"), H, W, t.a("up1"), 64, 64, A_RELU, nullptr, "train.fwd"));
     RC(t.conv(S[22], t.a("up1"), 2 * H, 2 * W, t.a("up2"), 64, 64, A_RELU, nullptr, "train.fwd"));
+    if (c->model == SR_TECOGAN) {
+        // generator output = tanh(SRNet + bilinear x4 (LR_t)) (reference TecoGAN.py:74-76); the clipped SRNet
+        // output is kept for the clip's mask
+        RC(t.conv(S[23], t.a("up2"), 4 * H, 4 * W, t.a("s_out"), 3, 3, A_CLIP01, nullptr, "train.fwd"));
+        HIPCHK(c, hipMemcpyAsync(d_est, t.a("s_out"), (size_t)B * H * W * 48 * 4, hipMemcpyDeviceToDevice, st));
+        LAUNCHCHK(c, "teco_epilogue", launch_teco_epilogue(d_est, d_lr_t, B, H, W, st));
+        return SR_OK;
+    }
     RC(t.conv(S[23], t.a("up2"), 4 * H, 4 * W, d_est, 3, 3, A_CLIP01, nullptr, "train.fwd"));
     return SR_OK;
 }
@@ -253,7 +261,8 @@ int train_backward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const fl
     const ConvLayer* SD = T->srnet_dg;
     const int so = 28;   // index of SRNet's first tensor
     // ---- losses (Keras: mean over all elements) and their gradients
-    LAUNCHCHK(c, "mse", launch_mse_grad(d_est, d_hr, t.a("g_est"), T->mse_part, T->d_loss, 16 * L0, 3, 16, 1, st));
+    LAUNCHCHK(c, "mse", launch_mse_grad(d_est, d_hr, t.a("g_est"), T->mse_part, T->d_loss, 16 * L0, 3, 16,
+                                           c->model == SR_TECOGAN ? t.a("s_out") : d_est, c->model == SR_TECOGAN, st));
     // ---- SRNet, reverse order (reference layers.py:66-76)
     RC(t.wgrad(so + 46, M_CONV, 64, 3, t.a("up2"), 64, t.a("g_est"), 16, 4 * H, 4 * W));
     RC(t.conv(SD[23], t.a("g_est"), 4 * H, 4 * W, cur, 64, 64, A_NONE, nullptr, "train.dgrad"));
@@ -291,7 +300,7 @@ int train_backward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const fl
         LAUNCHCHK(c, "hr_warp_bwd", launch_hr_warp_bwd(d_est_prev, d_flow, cur, t.a("g_fhr"), B, H, W, 64, st));
         HIPCHK(c, hipMemsetAsync(t.a("g_flow"), 0, (size_t)L0 * 16 * 4, st));
         LAUNCHCHK(c, "resize_bwd", launch_resize_bwd(t.a("g_fhr"), t.a("g_flow"), B, H, W, 2, 4, 16, 0, st));
-        LAUNCHCHK(c, "mse", launch_mse_grad(d_lr_warp, d_lr_t, t.a("g_lw"), T->mse_part, T->d_loss + 1, L0, 3, 3, 0, st));
+        LAUNCHCHK(c, "mse", launch_mse_grad(d_lr_warp, d_lr_t, t.a("g_lw"), T->mse_part, T->d_loss + 1, L0, 3, 3, nullptr, 0, st));
         LAUNCHCHK(c, "warp_bwd_flow", launch_warp_bwd_flow(d_lr_tm1, d_flow, t.a("g_lw"), t.a("g_flow"), B, H, W, 3, 16, 1, st));
     }
     RC(t.mask(t.a("g_flow"), d_flow, A_TANH, L0, 2, 16, 2));

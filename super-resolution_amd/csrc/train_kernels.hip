@@ -528,12 +528,14 @@ hipError_t launch_hr_warp_bwd(const float* est_prev, const float* flow, const fl
 }
 
 // ================================================================== mean-squared-error loss and its gradient
-// Keras: mean over every element (reference FRVSR.py:70).  g[p, c < C] = scale * (pred - target) (zeroed
-// where clip01_mask and pred sits on a clip bound: the gradient of SRNet's final clip), g[p, C..gcs) = 0;
+// Keras: mean over every element (reference FRVSR.py:70).  g[p, c < C] = scale * (pred - target), times the
+// derivative of the output non-linearity: tanh_out (TecoGAN's epilogue, TecoGAN.py:76): 1 - pred^2;
+// clip_src (SRNet's final clip[0,1], reference layers.py:76; = pred for FRVSR, the tensor before the
+// epilogue for TecoGAN): zero where it sits on a clip bound.  g[p, C..gcs) = 0;
 // partial[block] = sum (pred - target)^2 of the block's elements.
 __global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                        float* __restrict__ g, double* __restrict__ partial, long npix, int C,
-                                                       int gcs, float scale, int clip01_mask) {
+                                                       int gcs, float scale, const float* __restrict__ clip_src, int tanh_out) {
     __shared__ double red[256];
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     double sq = 0.0;
@@ -546,7 +548,11 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__
             const float d = a - target[p * C + c];
             sq = (double)d * d;
             gv = scale * d;
-            if (clip01_mask && !(a > 0.f && a < 1.f)) gv = 0.f;
+            if (tanh_out) gv *= 1.f - a * a;
+            if (clip_src) {
+                const float u = clip_src[p * C + c];
+                if (!(u > 0.f && u < 1.f)) gv = 0.f;
+            }
         }
         g[idx] = gv;
     }
@@ -575,10 +581,10 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
 size_t mse_workspace_bytes(long npix, int gcs) { return (size_t)blocks_for(npix * gcs, 256) * sizeof(double); }
 
 hipError_t launch_mse_grad(const float* pred, const float* target, float* g, double* partial, float* loss_out, long npix, int C,
-                           int gcs, int clip01_mask, hipStream_t s) {
+                           int gcs, const float* clip_src, int tanh_out, hipStream_t s) {
     const int nb = blocks_for(npix * gcs, 256);
     const double count = (double)npix * C;
-    hipLaunchKernelGGL(mse_grad_kernel, dim3(nb), dim3(256), 0, s, pred, target, g, partial, npix, C, gcs, (float)(2.0 / count), clip01_mask);
+    hipLaunchKernelGGL(mse_grad_kernel, dim3(nb), dim3(256), 0, s, pred, target, g, partial, npix, C, gcs, (float)(2.0 / count), clip_src, tanh_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, nb, 1.0 / count, loss_out);

@@ -125,3 +125,32 @@ def test_train_stage_runs_the_reference_loop(tmp_path, weights7):
     for _ in range(40):
         loss = m.frvsr.train_on_batch(x, y)
     assert loss[0] < 0.9 * first
+
+
+def test_tecogan_generator_pretraining_stage(tmp_path, weights7):
+    """TecoGAN.train(): the generator pre-training phase (reference TecoGAN.py:164-275) runs natively with
+    the halving learning-rate schedule and writes generator checkpoints; the adversarial phase says it is not built."""
+    from oracle import ref_train
+    t = build('tecogan', (16, 16, 3), tmp_path, weights7)
+    os.makedirs(tmp_path / 'clips')
+    np.save(tmp_path / 'clips' / '0.npy', (rn.synth_clip(31, 6, 80, 80, scale=4) * 255).astype(np.uint8))
+    t.configs['train'] = {'iterations': 4, 'batch_size': 1, 'c_frames': 3, 'sample_freq': 1, 'checkpoint_freq': 1,
+                          'info_freq': 1, 'seed': 3, 'pretrained_disc': None}
+    t.configs['data'].update(high_res=64)
+    assert t.generator.optimizer.lr == 5e-5                                   # TecoGAN.py:110
+    before = [a.copy() for a in weights7.values()]                            # train() loads cnn.pretrained_model first
+    with pytest.raises(NotImplementedError, match='adversarial'):
+        t.train()                                                            # iterations 0, 1 (< iterations / 2)
+    assert t.generator.optimizer.lr == 1e-4                                   # schedule value at i < 50k
+    assert (tmp_path / 'Checkpoints' / 'generator_model_weights_1.h5').exists() and (tmp_path / 'TecoGAN.yaml').exists()
+    after = t.generator.get_weights()
+    moved = max(np.abs(a - b).max() for a, b in zip(after, before))
+    assert 1e-4 <= moved <= 2.1e-4                                            # two Adam steps at 1e-4
+    # one more step on a hand-made batch against the oracle's tecogan step from the same weights
+    import utils
+    hr = utils.normalize(np.load(tmp_path / 'clips' / '0.npy')[None, :3, :64, :64])
+    x, y = t.make_train_batch(hr)
+    w_now = dict(zip(weights7.keys(), t.generator.get_weights()))
+    want_l, _, _ = ref_train.loss_and_grads(w_now, x[0], x[1], x[2], y[0], model='tecogan')
+    loss = t.generator.train_on_batch(x, y)
+    assert np.allclose(loss, want_l, rtol=1e-4)

@@ -137,7 +137,7 @@ def step_data(seed, B, h, w):
     return lr_t, lr_tm1, est, hr
 
 
-def conditioned_data(weights, B, h, w, seed0, tries=20):
+def conditioned_data(weights, B, h, w, seed0, tries=20, model="frvsr"):
     """A gradient is discontinuous where a ReLU / LeakyReLU / clip input or a warp coordinate crosses its
     kink or two pooling candidates tie; fp32 arithmetic that differs from the float64 oracle in the last
     bits falls on the other side of a kink that is closer than ~1e-6, and on these tiny images ONE flipped
@@ -147,13 +147,13 @@ def conditioned_data(weights, B, h, w, seed0, tries=20):
     that distance is crossed by one of the two signs.  First seed that passes, deterministic."""
     for seed in range(seed0, seed0 + tries):
         data = step_data(seed, B, h, w)
-        want_l, want_g, _ = ref_train.loss_and_grads(weights, *data)
+        want_l, want_g, _ = ref_train.loss_and_grads(weights, *data, model=model)
         rng = np.random.default_rng(seed + 7919)
         noise = [rng.uniform(-3e-6, 3e-6, a.shape) for a in data]
         stable = True
         for sign in (1.0, -1.0):
             moved = [a.astype(np.float64) + sign * n for a, n in zip(data, noise)]
-            _, g, _ = ref_train.loss_and_grads(weights, *moved)
+            _, g, _ = ref_train.loss_and_grads(weights, *moved, model=model)
             if max(rel_err(g[k], want_g[k]) for k in want_g) > 2e-4:
                 stable = False
                 break
@@ -195,6 +195,21 @@ def test_step_gradients_match_autograd(sh, weights7, B, h, w, dtype, tol):
         if dtype == "fp32":
             _, want_sub, _ = ref_train.loss_and_grads(weights7, *sub)
             check_grads(ctx, g1, want_sub, tol)
+    ctx.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-4), ("bf16x3", 1e-2)])
+def test_tecogan_generator_gradients(sh, weights7, dtype, tol):
+    """generator.train_on_batch of TecoGAN's pre-training (reference TecoGAN.py:112-113,228): the same two
+    losses on tanh(clip(SRNet) + bilinear x4 (LR)), i.e. the gradient also passes 1 - out^2 and the clip mask
+    of the tensor BEFORE the epilogue."""
+    B, h, w = 2, 16, 24
+    data, want_l, want_g = conditioned_data(weights7, B, h, w, 400, model="tecogan")
+    ctx = sh.Context(h, w, max_batch=B, dtype=dtype, model="tecogan")
+    ctx.load_weights(weights7)
+    losses, flat = ctx.train_grads(*data, read=True)
+    assert np.allclose(losses, want_l, rtol=1e-5 if dtype == "fp32" else 1e-4)
+    check_grads(ctx, flat, want_g, tol)
     ctx.close()
 
 
@@ -255,11 +270,6 @@ def test_train_on_batch_follows_keras_adam(sh, weights7, dtype):
 
 def test_training_is_refused_where_it_cannot_run(sh, weights7):
     ctx = sh.Context(16, 16, max_batch=1, dtype="bf16")
-    ctx.load_weights(weights7)
-    with pytest.raises(ValueError):
-        ctx.train_grads(*step_data(1, 1, 16, 16))
-    ctx.close()
-    ctx = sh.Context(16, 16, max_batch=1, dtype="fp32", model="tecogan")
     ctx.load_weights(weights7)
     with pytest.raises(ValueError):
         ctx.train_grads(*step_data(1, 1, 16, 16))

@@ -255,8 +255,10 @@ def test_out_of_scope_stages_say_so():
     m = FrameRecurrentVideoSR((16, 16, 3), (64, 64, 3), '/tmp/o', CFG)
     with pytest.raises(NotImplementedError):
         m.run()
+    t = TecoGAN((16, 16, 3), (64, 64, 3), '/tmp/o', dict(CFG, train={'iterations': 0, 'pretrained_disc': 'd.h5'}))
     with pytest.raises(NotImplementedError):
-        TecoGAN((16, 16, 3), (64, 64, 3), '/tmp/o', CFG).train()     # adversarial training: a later row
+        t.train()                                                    # adversarial phase: a later row
+    assert [TecoGAN.gen_learning_rate(i) for i in (0, 49999, 50000, 100000, 10 ** 6)] == [1e-4, 1e-4, 5e-5, 2.5e-5, 2.5e-5]
 
 
 def test_clip_loader_rejects_videos(tmp_path):
