@@ -90,6 +90,7 @@ struct WgradArgs {
     float* db;         // bias gradient [cout], or nullptr
     int B, H, W;       // input spatial dims
     int cin, cout, xcs, ycs, convt;
+    int x3;            // 1: operands split hi+lo bf16, three bf16 MFMAs per product (ctx dtype bf16x3); 0: fp32 MFMA
 };
 size_t wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int convt);
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);

@@ -171,6 +171,7 @@ struct Tape {
         wa.xcs = xcs;
         wa.ycs = ycs;
         wa.convt = mode == M_CONVT;
+        wa.x3 = P == P_BF16X3;
         const double px = (double)B * H * W;
         char nm[48];
         snprintf(nm, sizeof nm, "train.wgrad%s %d>%d @%dx%d", mode == M_CONVT ? "T" : "", cin, cout, H, W);
@@ -574,7 +575,7 @@ int conv_bwd_op(int device, int dtype, int convt, int B, int H, int W, int Cin, 
     float* d_db = d.get(Cout);
     float* d_part = d.get(wgrad_workspace_bytes(B, H, W, Cin, Cout, convt) / 4);
     if (!d_x || !d_dy || !d_w || !d_dw || !d_db || !d_part) return fail(nullptr, SR_ERR_HIP, "hipMalloc / copy failed");
-    WgradArgs wa = {d_x, d_dy, d_part, d_dw, d_db, B, H, W, Cin, Cout, Cin, Cout, convt};
+    WgradArgs wa = {d_x, d_dy, d_part, d_dw, d_db, B, H, W, Cin, Cout, Cin, Cout, convt, dtype == SR_BF16X3};
     LAUNCHCHK(nullptr, "wgrad", launch_wgrad(wa, nullptr));
     if (dx) {
         float* d_dx = d.get(npix * Cin);

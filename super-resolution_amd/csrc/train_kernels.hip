@@ -18,6 +18,8 @@
 #include "kernels.h"
 #include "gather_math.h"
 
+#include <algorithm>
+
 namespace sr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -36,11 +38,15 @@ struct WgradPlan {
     int R, S;            // rows / columns of one tap's matrix: conv (cin, cout), transposed conv (cout, cin)
     int nrb, ncolb, nblk, nslices;
     int part;            // floats of one (slice, block) partial: ntap x 32 x 32 accumulators + 64 bias lanes
+    int x3;              // bf16x3 kernel: work is cut in segments of 16 pixels of one row
+    int nsr;             // segments per row (x3)
 };
 
-static WgradPlan wgrad_plan(int B, int H, int W, int cin, int cout, int convt) {
+static WgradPlan wgrad_plan(int B, int H, int W, int cin, int cout, int convt, int x3) {
     WgradPlan p;
     p.mode = convt ? WG_CONVT : (cout <= 3 ? WG_TAPSN : WG_CONV);
+    p.x3 = x3 && p.mode != WG_TAPSN;
+    p.nsr = (W + 15) / 16;
     p.R = convt ? cout : cin;
     p.S = convt ? cin : cout;
     p.nrb = (p.R + 31) / 32;
@@ -52,14 +58,19 @@ static WgradPlan wgrad_plan(int B, int H, int W, int cin, int cout, int convt) {
     // waves run eight deep
     long ns = (p.mode == WG_TAPSN ? 8192 : 2048) / p.nblk;
     if (ns > pairs / 16) ns = pairs / 16;         // at least 16 MFMA k-steps per slice
+    if (p.x3) {
+        const long nseg = (long)B * H * p.nsr;
+        ns = 2048 / p.nblk;
+        if (ns > nseg / 2) ns = nseg / 2;         // at least two 16-pixel segments per slice
+    }
     if (ns < 1) ns = 1;
     p.nslices = (int)ns;
     return p;
 }
 
 size_t wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int convt) {
-    const WgradPlan p = wgrad_plan(B, H, W, cin, cout, convt);
-    return (size_t)p.nslices * p.nblk * p.part * sizeof(float);
+    const WgradPlan p = wgrad_plan(B, H, W, cin, cout, convt, 0), q = wgrad_plan(B, H, W, cin, cout, convt, 1);
+    return (size_t)std::max(p.nslices, q.nslices) * p.nblk * p.part * sizeof(float);
 }
 
 // Every load is unconditional from a clamped (always valid) address and masked afterwards: a branch per
@@ -185,6 +196,120 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, const Wgr
     out[NT * 1024 + lane] = bsum;
 }
 
+
+// ---- bf16x3 variant (ctx dtype bf16x3): v_mfma_f32_32x32x16_bf16 takes 16 PIXELS per instruction, a lane
+// (channel i, half kh) holding its channel at 8 consecutive pixels.  A wave works on segments of 16 pixels
+// of one image row: each lane reads its channel at the pixels of its half plus the halo the taps need
+// (conv: 10 pixels of rows y-1, y, y+1 of X; transposed conv: 18 pixels of rows 2y, 2y+1, 2y+2 of dY) --
+// still one 128-B line per half wave and load -- splits every value ONCE into hi + lo bf16 and builds the
+// three column taps of a row from the same registers (conv: windows shifted by 0, 1, 2 pixels; transposed
+// conv: even, odd, even+2 pixels).  Per tap hi*hi + hi*lo + lo*hi, fp32 accumulate: 27 MFMAs of 32 cycles
+// per 16 pixels instead of 72 fp32 MFMAs of 64 cycles.  Same partial layout and reduction as the fp32 kernel.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const WgradArgs a, const WgradPlan pl) {
+    constexpr int NW = MODE == WG_CONVT ? 18 : 10;   // window pixels per row per lane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, kh = lane >> 5;
+    const int gw = blockIdx.x * 4 + wave;
+    const int blk = gw % pl.nblk, slice = gw / pl.nblk;
+    if (slice >= pl.nslices) return;   // no barrier in this kernel
+    const int rb = blk / pl.ncolb, cb = blk - rb * pl.ncolb;
+    const int H = a.H, W = a.W;
+    const unsigned nrows = (unsigned)a.B * H;
+    const unsigned nseg = nrows * pl.nsr;
+    const unsigned per = (nseg + pl.nslices - 1) / pl.nslices;
+    const unsigned s0 = slice * per, s1 = min(s0 + per, nseg);
+    const int ch_a = rb * 32 + i, ch_b = cb * 32 + i;
+    const bool a_ok = ch_a < pl.R, b_ok = ch_b < pl.S;
+    // shifted operand (A, rows of the tap matrix) and plain operand (B, columns)
+    const float* pa = (MODE == WG_CONVT ? a.dy : a.x) + (a_ok ? ch_a : 0);
+    const float* pb = (MODE == WG_CONVT ? a.x : a.dy) + (b_ok ? ch_b : 0);
+    const int acs = MODE == WG_CONVT ? a.ycs : a.xcs, bcs = MODE == WG_CONVT ? a.xcs : a.ycs;
+    const int AW = MODE == WG_CONVT ? 2 * W : W, AH = MODE == WG_CONVT ? 2 * H : H;   // dims of the shifted tensor
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+    for (unsigned s = s0; s < s1; ++s) {
+        const unsigned r = s / pl.nsr;                    // row b*H + y of the un-shifted tensor
+        const int x0 = (s - r * pl.nsr) * 16 + 8 * kh;    // first pixel of this lane's half
+        const int y = r % H;
+        // plain operand: 8 pixels
+        float u[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool in = b_ok && x0 + e < W;
+            const float v = pb[in ? ((size_t)r * W + x0 + e) * bcs : 0];
+            u[e] = in ? v : 0.f;
+        }
+        // shifted operand: 3 rows x NW pixels
+        float v[3][NW];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            const int yy = MODE == WG_CONVT ? 2 * y + rr : y - 1 + rr;              // row inside its image
+            const size_t arow = MODE == WG_CONVT ? (size_t)2 * r + rr : (size_t)r + rr - 1;   // rows of all images are contiguous
+            const bool rok = a_ok && yy >= 0 && yy < AH;
+            const int xw0 = MODE == WG_CONVT ? 2 * x0 : x0 - 1;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const bool in = rok && xw0 + j >= 0 && xw0 + j < AW;
+                const float t = pa[in ? (arow * AW + xw0 + j) * acs : 0];
+                v[rr][j] = in ? t : 0.f;
+            }
+        }
+        bf16x8 bh, bl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bh[e] = (__bf16)u[e];
+            bl[e] = (__bf16)(u[e] - (float)bh[e]);
+        }
+        if constexpr (MODE == WG_CONVT) {
+            // the four output phases (rows 2y, 2y+1; all 16 columns of the half) cover every dY pixel once
+#pragma unroll
+            for (int j = 0; j < 16; ++j) bsum += v[0][j] + v[1][j];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum += u[e];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            __bf16 h[NW], l[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                h[j] = (__bf16)v[rr][j];
+                l[j] = (__bf16)(v[rr][j] - (float)h[j]);
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                bf16x8 ah, al;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int j = MODE == WG_CONVT ? kx + 2 * e : kx + e;
+                    ah[e] = h[j];
+                    al[e] = l[j];
+                }
+                f32x16& c = acc[rr * 3 + kx];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+            }
+        }
+    }
+    float* out = a.part + ((size_t)slice * pl.nblk + blk) * pl.part;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = 8 * (rr >> 2) + 4 * kh + (rr & 3);
+            out[t * 1024 + row * 32 + i] = acc[t][rr];
+        }
+    out[9 * 1024 + lane] = bsum;
+}
+
 // dw / db = sum of the slices' partials in slice order (deterministic).  One workgroup: 32 consecutive
 // outputs x 8 slice lanes; lane g adds slices g, g + 8, ... and the eight sums meet in LDS in lane order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
@@ -226,9 +351,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
-    const WgradPlan pl = wgrad_plan(a.B, a.H, a.W, a.cin, a.cout, a.convt);
+    const WgradPlan pl = wgrad_plan(a.B, a.H, a.W, a.cin, a.cout, a.convt, a.x3);
     const dim3 grid((pl.nblk * pl.nslices + 3) / 4), block(256);
-    if (pl.mode == WG_CONVT)
+    if (pl.x3 && pl.mode == WG_CONVT)
+        hipLaunchKernelGGL(wgrad_x3_kernel<WG_CONVT>, grid, block, 0, s, a, pl);
+    else if (pl.x3)
+        hipLaunchKernelGGL(wgrad_x3_kernel<WG_CONV>, grid, block, 0, s, a, pl);
+    else if (pl.mode == WG_CONVT)
         hipLaunchKernelGGL(wgrad_kernel<WG_CONVT>, grid, block, 0, s, a, pl);
     else if (pl.mode == WG_TAPSN)
         hipLaunchKernelGGL(wgrad_kernel<WG_TAPSN>, grid, block, 0, s, a, pl);
