@@ -27,6 +27,9 @@ struct sr_train_state {
     float* part = nullptr;              // wgrad partial sums
     double* mse_part = nullptr;
     float* d_loss = nullptr;            // [sr, flow]
+    // host batches: the two HR-sized inputs are copied on a second stream under FNet / the forward
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_est = nullptr, ev_hr = nullptr;
 };
 
 namespace {
@@ -141,6 +144,10 @@ int train_init(sr_ctx* c) {
     const size_t mse_bytes = std::max(mse_workspace_bytes((long)(Bz * L0 * 16), 16), mse_workspace_bytes((long)(Bz * L0), 3));
     HIPCHK(c, hipMalloc((void**)&T->mse_part, mse_bytes));
     HIPCHK(c, hipMalloc((void**)&T->d_loss, 2 * sizeof(float)));
+    HIPCHK(c, hipStreamCreateWithFlags(&T->copy_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&T->ev_start, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&T->ev_est, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&T->ev_hr, hipEventDisableTiming));
     return SR_OK;
 }
 
@@ -193,35 +200,39 @@ struct Tape {
     } while (0)
 
 // forward of reference FRVSR.py:58-63 with every layer output kept (fp32 NHWC, no planar trunk, no fused tail)
-int train_forward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const float* d_est_prev, float* d_est, float* d_lr_warp,
-                  float* d_flow) {
+// stage 1: FNet (needs only the two LR frames); stage 2: warps + SRNet (needs the previous estimate)
+int train_forward(Tape& t, int stage, const float* d_lr_t, const float* d_lr_tm1, const float* d_est_prev, float* d_est,
+                  float* d_lr_warp, float* d_flow) {
     sr_ctx* c = t.c;
     const int B = t.B, H = c->h, W = c->w;
     hipStream_t st = t.st;
-    LAUNCHCHK(c, "fnet.input", launch_fnet_input(d_lr_t, d_lr_tm1, t.a("x0"), 0, B, H, W, st));
     const ConvLayer* F = c->fnet;
-    // encoder
-    RC(t.conv(F[0], t.a("x0"), H, W, t.a("e0a"), 32, 32, A_LRELU, nullptr, "train.fwd"));
-    RC(t.conv(F[1], t.a("e0a"), H, W, t.a("e0b"), 32, 32, A_LRELU, nullptr, "train.fwd"));
-    LAUNCHCHK(c, "pool", launch_maxpool2(t.a("e0b"), t.a("p1"), 0, B, H, W, 32, st));
-    RC(t.conv(F[2], t.a("p1"), H / 2, W / 2, t.a("e1a"), 64, 64, A_LRELU, nullptr, "train.fwd"));
-    RC(t.conv(F[3], t.a("e1a"), H / 2, W / 2, t.a("e1b"), 64, 64, A_LRELU, nullptr, "train.fwd"));
-    LAUNCHCHK(c, "pool", launch_maxpool2(t.a("e1b"), t.a("p2"), 0, B, H / 2, W / 2, 64, st));
-    RC(t.conv(F[4], t.a("p2"), H / 4, W / 4, t.a("e2a"), 128, 128, A_LRELU, nullptr, "train.fwd"));
-    RC(t.conv(F[5], t.a("e2a"), H / 4, W / 4, t.a("e2b"), 128, 128, A_LRELU, nullptr, "train.fwd"));
-    LAUNCHCHK(c, "pool", launch_maxpool2(t.a("e2b"), t.a("p3"), 0, B, H / 4, W / 4, 128, st));
-    RC(t.conv(F[6], t.a("p3"), H / 8, W / 8, t.a("e3a"), 256, 256, A_LRELU, nullptr, "train.fwd"));
-    RC(t.conv(F[7], t.a("e3a"), H / 8, W / 8, t.a("e3b"), 256, 256, A_LRELU, nullptr, "train.fwd"));
-    // decoder
-    LAUNCHCHK(c, "resize", launch_resize2x(t.a("e3b"), t.a("u2"), 0, B, H / 8, W / 8, 256, st));
-    RC(t.conv(F[8], t.a("u2"), H / 4, W / 4, t.a("d2a"), 128, 128, A_LRELU, nullptr, "train.fwd"));
-    RC(t.conv(F[9], t.a("d2a"), H / 4, W / 4, t.a("d2b"), 128, 128, A_LRELU, nullptr, "train.fwd"));
-    LAUNCHCHK(c, "resize", launch_resize2x(t.a("d2b"), t.a("u1"), 0, B, H / 4, W / 4, 128, st));
-    RC(t.conv(F[10], t.a("u1"), H / 2, W / 2, t.a("d1a"), 64, 64, A_LRELU, nullptr, "train.fwd"));
-    RC(t.conv(F[11], t.a("d1a"), H / 2, W / 2, t.a("d1b"), 64, 64, A_LRELU, nullptr, "train.fwd"));
-    LAUNCHCHK(c, "resize", launch_resize2x(t.a("d1b"), t.a("u0"), 0, B, H / 2, W / 2, 64, st));
-    RC(t.conv(F[12], t.a("u0"), H, W, t.a("c13"), 32, 32, A_LRELU, nullptr, "train.fwd"));
-    RC(t.conv(F[13], t.a("c13"), H, W, d_flow, 2, 2, A_TANH, nullptr, "train.fwd"));
+    if (stage == 1) {
+        LAUNCHCHK(c, "fnet.input", launch_fnet_input(d_lr_t, d_lr_tm1, t.a("x0"), 0, B, H, W, st));
+        // encoder
+        RC(t.conv(F[0], t.a("x0"), H, W, t.a("e0a"), 32, 32, A_LRELU, nullptr, "train.fwd"));
+        RC(t.conv(F[1], t.a("e0a"), H, W, t.a("e0b"), 32, 32, A_LRELU, nullptr, "train.fwd"));
+        LAUNCHCHK(c, "pool", launch_maxpool2(t.a("e0b"), t.a("p1"), 0, B, H, W, 32, st));
+        RC(t.conv(F[2], t.a("p1"), H / 2, W / 2, t.a("e1a"), 64, 64, A_LRELU, nullptr, "train.fwd"));
+        RC(t.conv(F[3], t.a("e1a"), H / 2, W / 2, t.a("e1b"), 64, 64, A_LRELU, nullptr, "train.fwd"));
+        LAUNCHCHK(c, "pool", launch_maxpool2(t.a("e1b"), t.a("p2"), 0, B, H / 2, W / 2, 64, st));
+        RC(t.conv(F[4], t.a("p2"), H / 4, W / 4, t.a("e2a"), 128, 128, A_LRELU, nullptr, "train.fwd"));
+        RC(t.conv(F[5], t.a("e2a"), H / 4, W / 4, t.a("e2b"), 128, 128, A_LRELU, nullptr, "train.fwd"));
+        LAUNCHCHK(c, "pool", launch_maxpool2(t.a("e2b"), t.a("p3"), 0, B, H / 4, W / 4, 128, st));
+        RC(t.conv(F[6], t.a("p3"), H / 8, W / 8, t.a("e3a"), 256, 256, A_LRELU, nullptr, "train.fwd"));
+        RC(t.conv(F[7], t.a("e3a"), H / 8, W / 8, t.a("e3b"), 256, 256, A_LRELU, nullptr, "train.fwd"));
+        // decoder
+        LAUNCHCHK(c, "resize", launch_resize2x(t.a("e3b"), t.a("u2"), 0, B, H / 8, W / 8, 256, st));
+        RC(t.conv(F[8], t.a("u2"), H / 4, W / 4, t.a("d2a"), 128, 128, A_LRELU, nullptr, "train.fwd"));
+        RC(t.conv(F[9], t.a("d2a"), H / 4, W / 4, t.a("d2b"), 128, 128, A_LRELU, nullptr, "train.fwd"));
+        LAUNCHCHK(c, "resize", launch_resize2x(t.a("d2b"), t.a("u1"), 0, B, H / 4, W / 4, 128, st));
+        RC(t.conv(F[10], t.a("u1"), H / 2, W / 2, t.a("d1a"), 64, 64, A_LRELU, nullptr, "train.fwd"));
+        RC(t.conv(F[11], t.a("d1a"), H / 2, W / 2, t.a("d1b"), 64, 64, A_LRELU, nullptr, "train.fwd"));
+        LAUNCHCHK(c, "resize", launch_resize2x(t.a("d1b"), t.a("u0"), 0, B, H / 2, W / 2, 64, st));
+        RC(t.conv(F[12], t.a("u0"), H, W, t.a("c13"), 32, 32, A_LRELU, nullptr, "train.fwd"));
+        RC(t.conv(F[13], t.a("c13"), H, W, d_flow, 2, 2, A_TANH, nullptr, "train.fwd"));
+        return SR_OK;
+    }
     // warps
     LAUNCHCHK(c, "lr_warp", launch_warp3(d_lr_tm1, d_flow, d_lr_warp, B, H, W, st));
     LAUNCHCHK(c, "pre_srnet", launch_pre_srnet(d_flow, d_est_prev, d_lr_t, t.a("s_in"), nullptr, 0, B, H, W, st));
@@ -393,12 +404,23 @@ int grads_common(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const
     const size_t nlr = (size_t)B * c->h * c->w * 3 * 4, nhr = nlr * 16;
     hipStream_t st = c->stream;
     const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    // The two HR-sized inputs (31 MB each at 40 x 256 x 256) go over a second stream: a copy from pageable
+    // host memory blocks the calling thread, so FNet is enqueued first and runs under the copy of the
+    // previous estimate, the rest of the forward under the copy of the HR target.
+    hipStream_t cs = T->copy_stream;
+    HIPCHK(c, hipEventRecord(T->ev_start, st));                 // earlier work on the ctx stream may still read the buffers
+    HIPCHK(c, hipStreamWaitEvent(cs, T->ev_start, 0));
     HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, kind, st));
     HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, lr_tm1, nlr, kind, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, kind, st));
-    HIPCHK(c, hipMemcpyAsync(T->act["hr"], hr_t, nhr, kind, st));
     Tape t{c, T, B, c->prec, st};
-    if ((rc = train_forward(t, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
+    if ((rc = train_forward(t, 1, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, kind, cs));
+    HIPCHK(c, hipEventRecord(T->ev_est, cs));
+    HIPCHK(c, hipStreamWaitEvent(st, T->ev_est, 0));
+    if ((rc = train_forward(t, 2, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
+    HIPCHK(c, hipMemcpyAsync(T->act["hr"], hr_t, nhr, kind, cs));
+    HIPCHK(c, hipEventRecord(T->ev_hr, cs));
+    HIPCHK(c, hipStreamWaitEvent(st, T->ev_hr, 0));
     if ((rc = train_backward(t, c->d_lr_t, c->d_lr_tm1, c->d_est[0], T->act["hr"], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
     if (d_grads_out) HIPCHK(c, hipMemcpyAsync(d_grads_out, T->d_grad, (size_t)T->nparams * 4, hipMemcpyDeviceToDevice, st));
     float l[2] = {0.f, 0.f};
@@ -445,6 +467,12 @@ void train_free(sr_ctx* c) {
     for (auto p : fl)
         if (p) (void)hipFree(p);
     if (T->mse_part) (void)hipFree(T->mse_part);
+    if (T->copy_stream) {
+        (void)hipStreamSynchronize(T->copy_stream);
+        (void)hipStreamDestroy(T->copy_stream);
+    }
+    for (hipEvent_t e : {T->ev_start, T->ev_est, T->ev_hr})
+        if (e) (void)hipEventDestroy(e);
     for (auto& kv : T->act) (void)hipFree(kv.second);
     for (auto& L : T->fnet_dg) free_layer(L);
     for (auto& L : T->srnet_dg) free_layer(L);
