@@ -179,7 +179,8 @@ int sr_train_on_batch(sr_ctx* ctx, int B, const float* lr_t, const float* lr_tm1
                       const float* hr_t, float lr, float* losses);
 int64_t sr_train_iterations(const sr_ctx* ctx);   /* optimizer steps taken (Keras `iterations`) */
 
-/* Gradients of the single ops (host pointers, NHWC float32), for the parity tests against autograd:
+/* Gradients of the single ops (host pointers, NHWC float32), for the parity tests against autograd
+ * (dtype fp32 or bf16x3 selects the arithmetic of the convolution gradients):
  * Conv2D 3x3 'same' (x, w HWIO, dy) -> dx (nullable), dw (3,3,Cin,Cout), db (nullable);
  * Conv2DTranspose 3x3 s2 (x (B,H,W,Cin), w (3,3,Cout,Cin), dy (B,2H,2W,Cout)) -> dx, dw, db
  *   (dx needs Cout % 64 == 0, the layers of reference layers.py:71-74);
@@ -187,7 +188,7 @@ int64_t sr_train_iterations(const sr_ctx* ctx);   /* optimizer steps taken (Kera
  * dense_image_warp with respect to the flow. */
 int sr_op_conv3x3_bwd(int device, int dtype, int B, int H, int W, int Cin, int Cout, const float* x,
                       const float* w, const float* dy, float* dx, float* dw, float* db);
-int sr_op_convT3x3s2_bwd(int device, int B, int H, int W, int Cin, int Cout, const float* x,
+int sr_op_convT3x3s2_bwd(int device, int dtype, int B, int H, int W, int Cin, int Cout, const float* x,
                          const float* w, const float* dy, float* dx, float* dw, float* db);
 int sr_op_maxpool2_bwd(int device, int B, int H, int W, int C, const float* x, const float* gy, float* gx);
 int sr_op_resize_bilinear_bwd(int device, int B, int H, int W, int C, int s, const float* gy, float* gx);

@@ -98,6 +98,9 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);
 // relu_y (nullable, laid out like dx): the output of the ReLU that fed the layer, dx is zeroed where it is not positive
 hipError_t launch_dgrad_s2(const float* dy, const float* w, float* dx, const float* relu_y, int B, int H, int W, int cin,
                            int cout, int ycs, int xcs, hipStream_t s);
+// bf16x3 variant: wpack = bf16x3 forward-conv packing of the transposed conv's kernel read as HWIO (cin' = cout, cout' = cin)
+hipError_t launch_dgrad_s2_x3(const float* dy, const void* wpack, int nt, int wstride_cb, float* dx, const float* relu_y, int B,
+                              int H, int W, int cin, int cout, int ycs, int xcs, hipStream_t s);
 hipError_t launch_act_bwd(float* g, const float* y, int act, long npix, int C, int gcs, int ycs, hipStream_t s);
 hipError_t launch_maxpool2_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, hipStream_t s);
 hipError_t launch_resize_bwd(const float* gy, float* gx, int B, int H, int W, int C, int sc, int ocs, int accumulate, hipStream_t s);

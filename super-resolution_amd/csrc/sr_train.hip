@@ -111,11 +111,13 @@ int train_init(sr_ctx* c) {
                 W = 4 * w;
             }
             part_bytes = std::max(part_bytes, wgrad_workspace_bytes(B, H, W, cin, cout, mode == M_CONVT));
-            if (mode == M_CONVT || (is_f && i == 0)) continue;
+            if ((mode == M_CONVT && c->prec != P_BF16X3) || (is_f && i == 0)) continue;
             ConvLayer& D = is_f ? T->fnet_dg[i] : T->srnet_dg[i];
             plan_layer(D, c->prec, M_CONV, cout, cin);
             const float* wk = c->tensors[(is_f ? 0 : 28) + 2 * i].data.data();
-            if ((rc = upload_layer(c, D, c->prec, wk, nullptr, PK_DGRAD))) return rc;
+            // transposed conv (bf16x3): its kernel (kh,kw,out,in) read as HWIO is the stride-2 data-gradient conv's
+            // kernel; dgrad_s2_x3 reads it in the forward packing
+            if ((rc = upload_layer(c, D, c->prec, wk, nullptr, mode == M_CONVT ? PK_FWD : PK_DGRAD))) return rc;
             if ((rc = upload_ents(c, D.ents, &D.d_ents))) return rc;
         }
     }
@@ -282,13 +284,19 @@ int train_backward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const fl
     RC(t.wgrad(so + 44, M_CONVT, 64, 64, t.a("up1"), 64, cur, 64, 2 * H, 2 * W));
     {
         ProfScope ps(c, "train.dgrad_s2", 4.0 * L0 * 18 * 64 * 64, 4.0 * L0 * 4 * (4 * 64 + 64));
-        LAUNCHCHK(c, "dgrad_s2", launch_dgrad_s2(cur, T->d_params + T->off[so + 44], oth, t.a("up1"), B, 2 * H, 2 * W, 64, 64, 64, 64, st));
+        if (t.P == P_BF16X3)
+            LAUNCHCHK(c, "dgrad_s2", launch_dgrad_s2_x3(cur, SD[22].d_w, SD[22].nt, SD[22].wstride_cb, oth, t.a("up1"), B, 2 * H, 2 * W, 64, 64, 64, 64, st));
+        else
+            LAUNCHCHK(c, "dgrad_s2", launch_dgrad_s2(cur, T->d_params + T->off[so + 44], oth, t.a("up1"), B, 2 * H, 2 * W, 64, 64, 64, 64, st));
     }
     swap();   // ReLU mask of up1 applied in the kernel's store
     RC(t.wgrad(so + 42, M_CONVT, 64, 64, t.a("x10_"), 64, cur, 64, H, W));
     {
         ProfScope ps(c, "train.dgrad_s2", 1.0 * L0 * 18 * 64 * 64, 1.0 * L0 * 4 * (4 * 64 + 64));
-        LAUNCHCHK(c, "dgrad_s2", launch_dgrad_s2(cur, T->d_params + T->off[so + 42], oth, nullptr, B, H, W, 64, 64, 64, 64, st));
+        if (t.P == P_BF16X3)
+            LAUNCHCHK(c, "dgrad_s2", launch_dgrad_s2_x3(cur, SD[21].d_w, SD[21].nt, SD[21].wstride_cb, oth, nullptr, B, H, W, 64, 64, 64, 64, st));
+        else
+            LAUNCHCHK(c, "dgrad_s2", launch_dgrad_s2(cur, T->d_params + T->off[so + 42], oth, nullptr, B, H, W, 64, 64, 64, 64, st));
     }
     swap();   // cur = g_x
     char xn[16], yn[16];
@@ -608,7 +616,14 @@ int conv_bwd_op(int device, int dtype, int convt, int B, int H, int W, int Cin, 
     if (dx) {
         float* d_dx = d.get(npix * Cin);
         if (!d_dx) return fail(nullptr, SR_ERR_HIP, "hipMalloc failed");
-        if (convt) {
+        if (convt && dtype == SR_BF16X3) {
+            ConvLayer D;
+            plan_layer(D, dtype, M_CONV, Cout, Cin);
+            struct Guard { ConvLayer& l; ~Guard() { free_layer(l); } } guard{D};
+            if ((rc = upload_layer(nullptr, D, dtype, w, nullptr, PK_FWD))) return rc;
+            LAUNCHCHK(nullptr, "dgrad_s2", launch_dgrad_s2_x3(d_dy, D.d_w, D.nt, D.wstride_cb, d_dx, nullptr, B, H, W, Cin, Cout, Cout, Cin, nullptr));
+            HIPCHK(nullptr, hipDeviceSynchronize());   // before the guard frees the weights
+        } else if (convt) {
             LAUNCHCHK(nullptr, "dgrad_s2", launch_dgrad_s2(d_dy, d_w, d_dx, nullptr, B, H, W, Cin, Cout, Cout, Cin, nullptr));
         } else {
             ConvLayer D;
@@ -639,9 +654,9 @@ int sr_op_conv3x3_bwd(int device, int dtype, int B, int H, int W, int Cin, int C
     return conv_bwd_op(device, dtype, 0, B, H, W, Cin, Cout, x, w, dy, dx, dw, db);
 }
 
-int sr_op_convT3x3s2_bwd(int device, int B, int H, int W, int Cin, int Cout, const float* x, const float* w,
+int sr_op_convT3x3s2_bwd(int device, int dtype, int B, int H, int W, int Cin, int Cout, const float* x, const float* w,
                          const float* dy, float* dx, float* dw, float* db) {
-    return conv_bwd_op(device, SR_FP32, 1, B, H, W, Cin, Cout, x, w, dy, dx, dw, db);
+    return conv_bwd_op(device, dtype, 1, B, H, W, Cin, Cout, x, w, dy, dx, dw, db);
 }
 
 int sr_op_maxpool2_bwd(int device, int B, int H, int W, int C, const float* x, const float* gy, float* gx) {

@@ -452,6 +452,92 @@ hipError_t launch_dgrad_s2(const float* dy, const float* w, float* dx, const flo
     return hipGetLastError();
 }
 
+// bf16x3 variant (ctx dtype bf16x3): v_mfma_f32_32x32x16_bf16, a lane (pixel i, half kh) holds 8 consecutive
+// channels of its pixel (two 16-B loads, split hi + lo in registers); the weights are read as ready-made hi / lo
+// B fragments from a buffer packed like a forward conv's (sr_api.hip pack_entries on the transposed conv's
+// own kernel tensor, which read as HWIO IS the kernel of this stride-2 convolution: [chunk of 16 channels][tap]
+// [n block][hi, lo][lane] x 16 B), kept current by the device re-pack.  6 MFMAs of 32 cycles per 16 channels
+// and tap for 64 outputs instead of 16 fp32 MFMAs of 64 cycles.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NB>
+__global__ __launch_bounds__(256) void dgrad_s2_x3_kernel(const float* __restrict__ dy, const u32x4* __restrict__ wpack,
+                                                          float* __restrict__ dx, const float* __restrict__ relu_y,
+                                                          int B, int H, int W, int K, int N, int ycs, int xcs, int wstride_cb) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, kh = lane >> 5;
+    const unsigned npix = (unsigned)B * H * W;
+    const unsigned p0 = (blockIdx.x * 4 + wave) * 32;
+    if (p0 >= npix) return;
+    const int n0 = blockIdx.y * NB * 32;
+    const u32x4* wp = wpack + (size_t)blockIdx.y * wstride_cb + lane;
+    const unsigned p = p0 + i;
+    const bool valid = p < npix;
+    const int x = p % W;
+    const unsigned t1 = p / W;
+    const int y = t1 % H;
+    const int b = t1 / H;
+    const int nchunk = K / 16;
+    f32x16 acc[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    const size_t img = valid ? (size_t)b * 2 * H : 0;
+    for (int t = 0; t < 9; ++t) {
+        const int yy = 2 * y + t / 3, xx = 2 * x + t % 3;
+        const bool in = valid && yy < 2 * H && xx < 2 * W;
+        const float* src = dy + (in ? ((img + yy) * 2 * W + xx) * ycs : 0) + kh * 8;
+        for (int c = 0; c < nchunk; ++c) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(src + c * 16), u1 = *reinterpret_cast<const f32x4*>(src + c * 16 + 4);
+            const f32x4 v0 = in ? u0 : z, v1 = in ? u1 : z;
+            bf16x8 ah, al;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ah[e] = (__bf16)v0[e];
+                al[e] = (__bf16)(v0[e] - (float)ah[e]);
+                ah[4 + e] = (__bf16)v1[e];
+                al[4 + e] = (__bf16)(v1[e] - (float)ah[4 + e]);
+            }
+            const u32x4* wv = wp + (size_t)(c * 9 + t) * NB * 128;
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const bf16x8 wh = __builtin_bit_cast(bf16x8, wv[n * 128]), wl = __builtin_bit_cast(bf16x8, wv[n * 128 + 64]);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[n], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned row = p0 + 8 * (r >> 2) + 4 * kh + (r & 3);
+            const int ch = n0 + n * 32 + i;
+            if (row < npix && ch < N) {
+                float v = acc[n][r];
+                if (relu_y && !(relu_y[(size_t)row * xcs + ch] > 0.f)) v = 0.f;
+                dx[(size_t)row * xcs + ch] = v;
+            }
+        }
+}
+
+// wpack: bf16x3 buffer of a forward conv planned as (cin = cout of the transposed conv, cout = its cin); nt its
+// n blocks per output-channel block (1 or 2), wstride_cb its vectors per output-channel block
+hipError_t launch_dgrad_s2_x3(const float* dy, const void* wpack, int nt, int wstride_cb, float* dx, const float* relu_y, int B,
+                              int H, int W, int cin, int cout, int ycs, int xcs, hipStream_t s) {
+    if (cout % 16 || ycs % 4 || cin % 32 || (nt != 1 && nt != 2)) return hipErrorInvalidValue;
+    const long npix = (long)B * H * W;
+    const dim3 block(256), grid(blocks_for(npix, 128), (cin + 32 * nt - 1) / (32 * nt));
+    if (nt == 2)
+        hipLaunchKernelGGL(dgrad_s2_x3_kernel<2>, grid, block, 0, s, dy, (const u32x4*)wpack, dx, relu_y, B, H, W, cout, cin, ycs, xcs, wstride_cb);
+    else
+        hipLaunchKernelGGL(dgrad_s2_x3_kernel<1>, grid, block, 0, s, dy, (const u32x4*)wpack, dx, relu_y, B, H, W, cout, cin, ycs, xcs, wstride_cb);
+    return hipGetLastError();
+}
+
 // ================================================================== activation derivative from the OUTPUT
 // g[p, c] *= act'(.) expressed through y = act(.):  ReLU y > 0; LeakyReLU(0.2) y > 0 ? 1 : 0.2;
 // tanh 1 - y^2; clip[0,1] 0 < y < 1  (Keras / TF and torch agree away from the kinks)

@@ -60,7 +60,7 @@ SIGNATURES = {
     "sr_train_on_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_float, _f32p]),
     "sr_train_iterations": (C.c_int64, [_vp]),
     "sr_op_conv3x3_bwd": (C.c_int, [C.c_int] * 7 + [_vp] * 6),
-    "sr_op_convT3x3s2_bwd": (C.c_int, [C.c_int] * 6 + [_vp] * 6),
+    "sr_op_convT3x3s2_bwd": (C.c_int, [C.c_int] * 7 + [_vp] * 6),
     "sr_op_maxpool2_bwd": (C.c_int, [C.c_int] * 5 + [_vp] * 3),
     "sr_op_resize_bilinear_bwd": (C.c_int, [C.c_int] * 6 + [_vp] * 2),
     "sr_op_warp_bwd_flow": (C.c_int, [C.c_int] * 5 + [_vp] * 4),
@@ -372,7 +372,7 @@ def conv3x3_bwd(x, w, dy, dtype="fp32", want_dx=True, device=0):
     return dx, dw, db
 
 
-def conv_transpose3x3_s2_bwd(x, w, dy, want_dx=True, device=0):
+def conv_transpose3x3_s2_bwd(x, w, dy, dtype="fp32", want_dx=True, device=0):
     x, w, dy = _f32(x), _f32(w), _f32(dy)
     B, H, W, Cin = x.shape
     Cout = w.shape[2]
@@ -380,7 +380,7 @@ def conv_transpose3x3_s2_bwd(x, w, dy, want_dx=True, device=0):
         raise ValueError(f"kernel {w.shape} / dy {dy.shape} do not match x {x.shape}")
     dx = np.empty_like(x) if want_dx else None
     dw, db = np.empty_like(w), np.empty(Cout, np.float32)
-    _check(lib().sr_op_convT3x3s2_bwd(device, B, H, W, Cin, Cout, _ptr(x), _ptr(w), _ptr(dy),
+    _check(lib().sr_op_convT3x3s2_bwd(device, DTYPES[dtype], B, H, W, Cin, Cout, _ptr(x), _ptr(w), _ptr(dy),
                                       _ptr(dx) if want_dx else None, _ptr(dw), _ptr(db)))
     return dx, dw, db
 

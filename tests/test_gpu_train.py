@@ -61,18 +61,19 @@ def test_conv3x3_bwd(sh, B, H, W, Cin, Cout, dtype):
     assert rel_err(dx, xt.grad.permute(0, 2, 3, 1).numpy()) <= (2e-4 if dtype == "fp32" else 5e-4)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 8, 8, 64, 64), (1, 5, 7, 64, 64), (1, 16, 12, 32, 64), (1, 4, 36, 64, 128)])
-def test_conv_transpose_bwd(sh, B, H, W, Cin, Cout):
+def test_conv_transpose_bwd(sh, B, H, W, Cin, Cout, dtype):
     x, w, dy = rnd(4, B, H, W, Cin), rnd(5, 3, 3, Cout, Cin, lo=-0.2, hi=0.2), rnd(6, B, 2 * H, 2 * W, Cout)
     xt = t64(x).permute(0, 3, 1, 2).requires_grad_(True)
     wt = t64(w).requires_grad_(True)
     bt = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
     y = rt.conv_transpose3x3_s2_same(xt, wt.permute(3, 2, 0, 1), bt)
     y.backward(t64(dy).permute(0, 3, 1, 2))
-    dx, dw, db = sh.conv_transpose3x3_s2_bwd(x, w, dy)
+    dx, dw, db = sh.conv_transpose3x3_s2_bwd(x, w, dy, dtype=dtype)
     assert rel_err(dw, wt.grad.numpy()) <= 2e-4
     assert rel_err(db, bt.grad.numpy()) <= 2e-4
-    assert rel_err(dx, xt.grad.permute(0, 2, 3, 1).numpy()) <= 2e-4
+    assert rel_err(dx, xt.grad.permute(0, 2, 3, 1).numpy()) <= (2e-4 if dtype == "fp32" else 5e-4)
 
 
 def test_conv_transpose_bwd_rejects_unsupported(sh):
