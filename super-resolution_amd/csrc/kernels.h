@@ -101,6 +101,9 @@ hipError_t launch_dgrad_s2(const float* dy, const float* w, float* dx, const flo
 // bf16x3 variant: wpack = bf16x3 forward-conv packing of the transposed conv's kernel read as HWIO (cin' = cout, cout' = cin)
 hipError_t launch_dgrad_s2_x3(const float* dy, const void* wpack, int nt, int wstride_cb, float* dx, const float* relu_y, int B,
                               int H, int W, int cin, int cout, int ycs, int xcs, hipStream_t s);
+// data gradient of a 3x3 conv with <= 3 outputs (w HWIO), activation derivative of the input's producer folded in (y nullable)
+hipError_t launch_dgrad_few(const float* g, const float* w, float* dx, const float* y, int act, int B, int H, int W, int cin,
+                            int cout, int gcs, int xcs, hipStream_t s);
 hipError_t launch_act_bwd(float* g, const float* y, int act, long npix, int C, int gcs, int ycs, hipStream_t s);
 hipError_t launch_maxpool2_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, hipStream_t s);
 hipError_t launch_resize_bwd(const float* gy, float* gx, int B, int H, int W, int C, int sc, int ocs, int accumulate, hipStream_t s);

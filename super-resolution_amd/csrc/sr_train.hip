@@ -111,7 +111,7 @@ int train_init(sr_ctx* c) {
                 W = 4 * w;
             }
             part_bytes = std::max(part_bytes, wgrad_workspace_bytes(B, H, W, cin, cout, mode == M_CONVT));
-            if ((mode == M_CONVT && c->prec != P_BF16X3) || (is_f && i == 0)) continue;
+            if ((mode == M_CONVT && c->prec != P_BF16X3) || (is_f && i == 0) || cout <= 3) continue;   // <= 3 outputs: dgrad_few reads the master weights
             ConvLayer& D = is_f ? T->fnet_dg[i] : T->srnet_dg[i];
             plan_layer(D, c->prec, M_CONV, cout, cin);
             const float* wk = c->tensors[(is_f ? 0 : 28) + 2 * i].data.data();
@@ -129,7 +129,7 @@ int train_init(sr_ctx* c) {
         {"p2", L2 * 64}, {"e2a", L2 * 128}, {"e2b", L2 * 128}, {"p3", L3 * 128}, {"e3a", L3 * 256}, {"e3b", L3 * 256},
         {"u2", L2 * 256}, {"d2a", L2 * 128}, {"d2b", L2 * 128}, {"u1", L1 * 128}, {"d1a", L1 * 64}, {"d1b", L1 * 64},
         {"u0", L0 * 64}, {"c13", L0 * 32}, {"s_in", L0 * 64}, {"up1", L0 * 4 * 64}, {"up2", L0 * 16 * 64},
-        {"gA", L0 * 16 * 64}, {"gB", L0 * 16 * 64}, {"g_est", L0 * 16 * 16}, {"g_flow", L0 * 16}, {"g_fhr", L0 * 16 * 2},
+        {"gA", L0 * 16 * 64}, {"gB", L0 * 16 * 64}, {"g_est", L0 * 16 * 4}, {"g_flow", L0 * 16}, {"g_fhr", L0 * 16 * 2},
         {"g_lw", L0 * 3}, {"hr", L0 * 48},
         {"s_out", c->model == SR_TECOGAN ? L0 * 48 : 0}};   // SRNet's clipped output before TecoGAN's tanh epilogue
     for (auto& p : plan)
@@ -143,7 +143,7 @@ int train_init(sr_ctx* c) {
             if ((rc = talloc(c, nm, Bz * L0 * 64))) return rc;
         }
     }
-    const size_t mse_bytes = std::max(mse_workspace_bytes((long)(Bz * L0 * 16), 16), mse_workspace_bytes((long)(Bz * L0), 3));
+    const size_t mse_bytes = std::max(mse_workspace_bytes((long)(Bz * L0 * 16), 4), mse_workspace_bytes((long)(Bz * L0), 3));
     HIPCHK(c, hipMalloc((void**)&T->mse_part, mse_bytes));
     HIPCHK(c, hipMalloc((void**)&T->d_loss, 2 * sizeof(float)));
     HIPCHK(c, hipStreamCreateWithFlags(&T->copy_stream, hipStreamNonBlocking));
@@ -275,12 +275,15 @@ int train_backward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const fl
     const ConvLayer* SD = T->srnet_dg;
     const int so = 28;   // index of SRNet's first tensor
     // ---- losses (Keras: mean over all elements) and their gradients
-    LAUNCHCHK(c, "mse", launch_mse_grad(d_est, d_hr, t.a("g_est"), T->mse_part, T->d_loss, 16 * L0, 3, 16,
+    LAUNCHCHK(c, "mse", launch_mse_grad(d_est, d_hr, t.a("g_est"), T->mse_part, T->d_loss, 16 * L0, 3, 4,
                                            c->model == SR_TECOGAN ? t.a("s_out") : d_est, c->model == SR_TECOGAN, st));
     // ---- SRNet, reverse order (reference layers.py:66-76)
-    RC(t.wgrad(so + 46, M_CONV, 64, 3, t.a("up2"), 64, t.a("g_est"), 16, 4 * H, 4 * W));
-    RC(t.conv(SD[23], t.a("g_est"), 4 * H, 4 * W, cur, 64, 64, A_NONE, nullptr, "train.dgrad"));
-    RC(t.mask(cur, t.a("up2"), A_RELU, 16 * L0, 64, 64, 64));
+    RC(t.wgrad(so + 46, M_CONV, 64, 3, t.a("up2"), 64, t.a("g_est"), 4, 4 * H, 4 * W));
+    {   // data gradient of the 64->3 conv with up2's ReLU mask in the store: one pass over the step's largest tensor
+        ProfScope ps(c, "train.dgrad_few", 16.0 * L0 * 54 * 64, 16.0 * L0 * 4 * (64 + 64 + 3));
+        LAUNCHCHK(c, "dgrad_few", launch_dgrad_few(t.a("g_est"), T->d_params + T->off[so + 46], cur, t.a("up2"), A_RELU, B, 4 * H, 4 * W,
+                                                   64, 3, 4, 64, st));
+    }
     RC(t.wgrad(so + 44, M_CONVT, 64, 64, t.a("up1"), 64, cur, 64, 2 * H, 2 * W));
     {
         ProfScope ps(c, "train.dgrad_s2", 4.0 * L0 * 18 * 64 * 64, 4.0 * L0 * 4 * (4 * 64 + 64));
@@ -344,8 +347,11 @@ int train_backward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const fl
         return SR_OK;
     };
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8;
-    RC(conv_bwd(13, "c13", 32, t.a("g_flow"), 16, H, W, cur));
-    RC(t.mask(cur, t.a("c13"), A_LRELU, L0, 32, 32, 32));
+    RC(conv_bwd(13, "c13", 32, t.a("g_flow"), 16, H, W, nullptr));
+    {   // flow head 32->2: data gradient with c13's LeakyReLU derivative in the store
+        ProfScope ps(c, "train.dgrad_few", 1.0 * L0 * 36 * 32, 1.0 * L0 * 4 * (32 + 32 + 2));
+        LAUNCHCHK(c, "dgrad_few", launch_dgrad_few(t.a("g_flow"), T->d_params + T->off[26], cur, t.a("c13"), A_LRELU, B, H, W, 32, 2, 16, 32, st));
+    }
     RC(conv_bwd(12, "u0", 64, cur, 32, H, W, oth));
     swap();
     RC(resize_bwd(H1, W1, 64));
@@ -625,6 +631,11 @@ int conv_bwd_op(int device, int dtype, int convt, int B, int H, int W, int Cin, 
             HIPCHK(nullptr, hipDeviceSynchronize());   // before the guard frees the weights
         } else if (convt) {
             LAUNCHCHK(nullptr, "dgrad_s2", launch_dgrad_s2(d_dy, d_w, d_dx, nullptr, B, H, W, Cin, Cout, Cout, Cin, nullptr));
+        } else if (Cout <= 3 && Cin % 16 == 0 && Cin <= 64) {   // the training step's path for the 64->3 and 32->2 layers
+            float* d_dy4 = d.get(npix * 4);
+            if (!d_dy4) return fail(nullptr, SR_ERR_HIP, "hipMalloc failed");
+            LAUNCHCHK(nullptr, "pad_channels", launch_pad_channels(d_dy, d_dy4, 0, (long)npix, Cout, 4, nullptr));
+            LAUNCHCHK(nullptr, "dgrad_few", launch_dgrad_few(d_dy4, d_w, d_dx, nullptr, A_NONE, B, H, W, Cin, Cout, 4, Cin, nullptr));
         } else {
             ConvLayer D;
             plan_layer(D, dtype, M_CONV, Cout, Cin);

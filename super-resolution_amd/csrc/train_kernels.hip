@@ -538,6 +538,70 @@ hipError_t launch_dgrad_s2_x3(const float* dy, const void* wpack, int nt, int ws
     return hipGetLastError();
 }
 
+// ================================================================== data gradient of a conv with <= 3 outputs
+// dX[y,x,ci] = sum_{ky,kx,co} dY[y+1-ky, x+1-kx, co] * w[ky,kx,ci,co]: K = 9*cout <= 27 products per output
+// element, so the layer (SRNet's 64->3 at HR resolution, FNet's 32->2) is bound by WRITING dX (bound: HBM):
+// plain FMAs, the 27 x cin weights in LDS, the 27 gathered dY values in registers, 16 channels per thread,
+// and the derivative of the activation that produced this conv's input folded into the store (act / y),
+// which saves the separate mask pass over the largest tensor of the step (4h x 4w x 64).
+// One workgroup = 64 consecutive pixels x (cin / 16) waves; a wave owns 16 output channels, so its weights are
+// wave-uniform and come through scalar loads straight into the FMAs (no LDS), a lane owns one pixel and
+// reads the dY taps as one 16-byte load each (the four waves share them in L1).
+__global__ __launch_bounds__(256) void dgrad_few_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                        float* __restrict__ dx, const float* __restrict__ y, int act,
+                                                        int B, int H, int W, int cin, int cout, int gcs, int xcs) {
+    const int lane = threadIdx.x & 63;
+    const int c0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16;
+    const long npix = (long)B * H * W;
+    const long p = (long)blockIdx.x * 64 + lane;
+    if (p >= npix) return;
+    const int x = p % W;
+    const int yy = (p / W) % H;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int sy = yy + 1 - tap / 3, sx = x + 1 - tap % 3;
+        const bool in = sy >= 0 && sy < H && sx >= 0 && sx < W;
+        const f32x4 u = *reinterpret_cast<const f32x4*>(g + (in ? (p + (1 - tap / 3) * W + (1 - tap % 3)) * gcs : 0));
+        const float* wt = w + ((size_t)tap * cin + c0) * cout;   // wave-uniform: scalar loads
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+            if (co < cout) {                                     // uniform
+                const float gv = in ? u[co] : 0.f;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[c] += gv * wt[c * cout + co];
+            }
+        }
+    }
+    float* o = dx + p * xcs + c0;
+    const float* ym = y ? y + p * xcs + c0 : nullptr;
+    const float neg = act == A_LRELU ? 0.2f : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        if (ym) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(ym + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= m[e] > 0.f ? 1.f : neg;
+        }
+        *reinterpret_cast<f32x4*>(o + 4 * q) = v;
+    }
+}
+
+// cin 16 .. 64 in steps of 16, cout <= 3, gcs and xcs multiples of 4 (dY rows are read 16 bytes at a time, so the
+// tensor must be padded to 4 channels); y (nullable, laid out like dx) with act A_RELU / A_LRELU
+hipError_t launch_dgrad_few(const float* g, const float* w, float* dx, const float* y, int act, int B, int H, int W, int cin,
+                            int cout, int gcs, int xcs, hipStream_t s) {
+    if (cin % 16 || cin > 64 || cout > 3 || cout < 1 || xcs % 4 || gcs % 4 || (y && act != A_RELU && act != A_LRELU))
+        return hipErrorInvalidValue;
+    const long npix = (long)B * H * W;
+    hipLaunchKernelGGL(dgrad_few_kernel, dim3(blocks_for(npix, 64)), dim3(64 * (cin / 16)), 0, s, g, w, dx, y, act, B, H, W, cin,
+                       cout, gcs, xcs);
+    return hipGetLastError();
+}
+
 // ================================================================== activation derivative from the OUTPUT
 // g[p, c] *= act'(.) expressed through y = act(.):  ReLU y > 0; LeakyReLU(0.2) y > 0 ? 1 : 0.2;
 // tanh 1 - y^2; clip[0,1] 0 < y < 1  (Keras / TF and torch agree away from the kinks)
