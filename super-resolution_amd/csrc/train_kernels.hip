@@ -64,8 +64,47 @@ static WgradPlan wgrad_plan(int B, int H, int W, int cin, int cout, int convt, i
         if (ns > nseg / 2) ns = nseg / 2;         // at least two 16-pixel segments per slice
     }
     if (ns < 1) ns = 1;
-    p.nslices = (int)ns;
+    // 9-tap kernels: the four waves of a workgroup take four consecutive slices of ONE block and add their
+    // accumulators through LDS before writing, so a launch leaves a quarter of the partials to reduce
+    p.nslices = p.mode == WG_TAPSN ? (int)ns : (int)((ns + 3) / 4);
     return p;
+}
+
+// workgroup -> (block, slice group) for the 9-tap kernels: workgroup ids go round-robin over the 8 XCDs, so the
+// XCD index is kept in the slice group and the blocks of one group (which read the same pixels) share an L2
+struct WgId {
+    int blk, grp;
+};
+__device__ __forceinline__ WgId wg_decode(const WgradPlan& pl) {
+    const int q = blockIdx.x >> 3;
+    WgId id;
+    id.blk = q % pl.nblk;
+    id.grp = (q / pl.nblk) * 8 + (blockIdx.x & 7);
+    return id;
+}
+static int wg_grid(const WgradPlan& pl) { return 8 * pl.nblk * ((pl.nslices + 7) / 8); }
+
+// sum of the four waves' accumulators in wave order (deterministic), result in wave 0
+template <int NT>
+__device__ __forceinline__ void wg_combine(f32x16 (&acc)[NT], float& bsum, int wave, int lane, float* red) {
+    for (int k = 1; k < 4; ++k) {
+        if (wave == k) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 64 + lane] = acc[t][r];
+            red[NT * 1024 + lane] = bsum;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += red[(t * 16 + r) * 64 + lane];
+            bsum += red[NT * 1024 + lane];
+        }
+        __syncthreads();
+    }
 }
 
 size_t wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int convt) {
@@ -77,19 +116,32 @@ size_t wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int convt) 
 // load would serialise them and force a full vmcnt(0) before the MFMAs; this way the next k-step's ten
 // loads are in flight while the current one multiplies.
 template <int MODE>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, const WgradPlan pl) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const WgradPlan pl) {
     constexpr int NT = MODE == WG_TAPSN ? 1 : 9;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, kh = lane >> 5;
-    const int gw = blockIdx.x * 4 + wave;
-    const int blk = gw % pl.nblk, slice = gw / pl.nblk;
-    if (slice >= pl.nslices) return;   // no barrier in this kernel
+    __shared__ float red[MODE == WG_TAPSN ? 1 : 9 * 1024 + 64];
+    int blk, slice, wslice, nws;
+    if constexpr (MODE == WG_TAPSN) {
+        const int gw = blockIdx.x * 4 + wave;
+        blk = gw % pl.nblk;
+        slice = wslice = gw / pl.nblk;
+        nws = pl.nslices;
+        if (slice >= pl.nslices) return;   // no barrier on this path
+    } else {
+        const WgId id = wg_decode(pl);
+        blk = id.blk;
+        slice = id.grp;
+        if (slice >= pl.nslices) return;   // uniform for the workgroup
+        wslice = slice * 4 + wave;
+        nws = pl.nslices * 4;
+    }
     const int rb = blk / pl.ncolb, cb = blk - rb * pl.ncolb;
     const int H = a.H, W = a.W;
     const unsigned npix = (unsigned)a.B * H * W;
     const unsigned pairs = (npix + 1) / 2;
-    const unsigned per = (pairs + pl.nslices - 1) / pl.nslices;
-    const unsigned q0 = slice * per, q1 = min(q0 + per, pairs);
+    const unsigned per = (pairs + nws - 1) / nws;
+    const unsigned q0 = min((unsigned)wslice * per, pairs), q1 = min(q0 + per, pairs);
     // channel of this lane in the A (row) and B (column) operands
     const int ch_a = rb * 32 + i;
     const bool a_ok = ch_a < pl.R;
@@ -185,6 +237,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, const Wgr
         for (int t = 0; t < NT; ++t) av[t] = an[t];
         bv = bn;
     }
+    if constexpr (MODE != WG_TAPSN) {
+        wg_combine<NT>(acc, bsum, wave, lane, red);
+        if (wave != 0) return;
+    }
     float* out = a.part + ((size_t)slice * pl.nblk + blk) * pl.part;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -212,15 +268,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const WgradArgs a, con
     constexpr int NW = MODE == WG_CONVT ? 18 : 10;   // window pixels per row per lane
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, kh = lane >> 5;
-    const int gw = blockIdx.x * 4 + wave;
-    const int blk = gw % pl.nblk, slice = gw / pl.nblk;
-    if (slice >= pl.nslices) return;   // no barrier in this kernel
+    __shared__ float red[9 * 1024 + 64];
+    const WgId id = wg_decode(pl);
+    const int blk = id.blk, slice = id.grp;
+    if (slice >= pl.nslices) return;   // uniform for the workgroup
     const int rb = blk / pl.ncolb, cb = blk - rb * pl.ncolb;
     const int H = a.H, W = a.W;
     const unsigned nrows = (unsigned)a.B * H;
     const unsigned nseg = nrows * pl.nsr;
-    const unsigned per = (nseg + pl.nslices - 1) / pl.nslices;
-    const unsigned s0 = slice * per, s1 = min(s0 + per, nseg);
+    const unsigned per = (nseg + pl.nslices * 4 - 1) / (pl.nslices * 4);
+    const unsigned s0 = min((unsigned)(slice * 4 + wave) * per, nseg), s1 = min(s0 + per, nseg);
     const int ch_a = rb * 32 + i, ch_b = cb * 32 + i;
     const bool a_ok = ch_a < pl.R, b_ok = ch_b < pl.S;
     // shifted operand (A, rows of the tap matrix) and plain operand (B, columns)
@@ -299,6 +356,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const WgradArgs a, con
             }
         }
     }
+    wg_combine<9>(acc, bsum, wave, lane, red);
+    if (wave != 0) return;
     float* out = a.part + ((size_t)slice * pl.nblk + blk) * pl.part;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -352,7 +411,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
     const WgradPlan pl = wgrad_plan(a.B, a.H, a.W, a.cin, a.cout, a.convt, a.x3);
-    const dim3 grid((pl.nblk * pl.nslices + 3) / 4), block(256);
+    const dim3 grid(pl.mode == WG_TAPSN ? (pl.nblk * pl.nslices + 3) / 4 : wg_grid(pl)), block(256);
     if (pl.x3 && pl.mode == WG_CONVT)
         hipLaunchKernelGGL(wgrad_x3_kernel<WG_CONVT>, grid, block, 0, s, a, pl);
     else if (pl.x3)
