@@ -158,6 +158,29 @@ def cpu_baseline(weights, lr):
                       "184x320 -> 736x1280; the reference TF1/Keras CPU path cannot run here"}
 
 
+def train_step_rate(weights, dtype, B=40, h=64, steps=5):
+    """Extra line (not the headline): the native training step (SURVEY.md section 8 f rank 1) at the reference's
+    config 4 -- train_on_batch on batch_size 4 x c_frames 10 = 40 samples of 64x64 LR (FRVSR_example.yaml,
+    FRVSR.py:154-156), host numpy batch in, Adam step and weight re-pack included."""
+    import sr_hip
+    rng = np.random.default_rng(0)
+    data = [rng.random((B, h, h, 3), dtype=np.float32), rng.random((B, h, h, 3), dtype=np.float32),
+            rng.random((B, 4 * h, 4 * h, 3), dtype=np.float32), rng.random((B, 4 * h, 4 * h, 3), dtype=np.float32)]
+    ctx = sr_hip.Context(h, h, max_batch=B, dtype=dtype)
+    ctx.load_weights(weights)
+    for _ in range(2):
+        ctx.train_on_batch(*data)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = ctx.train_on_batch(*data)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / steps
+    ctx.close()
+    return {"workload": f"FRVSR train_on_batch, {B} samples of {h}x{h} LR -> {4 * h}x{4 * h} HR, Adam, host batch in",
+            "dtype": dtype, "ms_per_step": round(dt * 1e3, 3), "samples_per_s": round(B / dt, 1),
+            "algorithmic_tflops": round(3 * FLOP_PER_LR_PX * h * h * B / dt / 1e12, 1), "loss": round(float(loss[0]), 5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,6 +274,7 @@ def main():
             c2.close()
         out["other_dtypes"] = {"unit": "frames/s", **others}
         if world == 1:
+            out["train_step"] = train_step_rate(weights, args.dtype if args.dtype != "bf16" else "bf16x3")
             out["cpu_baseline"] = cpu_baseline(weights, lr)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -72,8 +72,16 @@ class GradBuffer:
     def reduce(self, losses):
         """Sum-average gradient and losses over the ranks; returns the averaged losses as floats."""
         import torch
+        import torch.distributed as dist
         self.losses.copy_(torch.tensor(losses, dtype=torch.float32))
-        mean_over_ranks_(self.t)
-        mean_over_ranks_(self.losses)
+        if dist.is_initialized() and dist.get_backend() == 'gloo':
+            # rehearsal without RCCL (several ranks on one GPU, CPU-only collectives): stage through the host
+            for t in (self.t, self.losses):
+                h = t.cpu()
+                mean_over_ranks_(h)
+                t.copy_(h)
+        else:
+            mean_over_ranks_(self.t)
+            mean_over_ranks_(self.losses)
         torch.cuda.synchronize(self.t.device)     # libsr_hip's stream is not torch's: finish before Adam reads
         return [float(v) for v in self.losses.cpu()]

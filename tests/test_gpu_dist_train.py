@@ -1,0 +1,86 @@
+"""Data-parallel training end to end on the GPU box: two processes (both on cuda:0, gloo for the exchange because
+RCCL wants one GPU per rank) run GeneratorModel.train_on_batch on their halves of a batch -- sr_train_grads into
+the torch gradient buffer, mean over the ranks, sr_train_apply -- and must end with the weights a single
+process gets from the whole batch.  On a multi-GPU node the same code runs with backend nccl (= RCCL)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batch(B, h, w):
+    rng = np.random.default_rng(77)
+    return [rng.random((B, h, w, 3), dtype=np.float32), rng.random((B, h, w, 3), dtype=np.float32),
+            rng.random((B, 4 * h, 4 * w, 3), dtype=np.float32), rng.random((B, 4 * h, 4 * w, 3), dtype=np.float32)]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", SR_DIST_BACKEND="gloo")
+    for p in (ROOT, os.path.join(ROOT, "super-resolution_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import dp
+    from layers import Adam, GeneratorCore, GeneratorModel
+    from oracle import ref_numpy as rn
+    core = GeneratorCore((16, 16, 3), dtype="fp32", device=0, seed=100 + rank)      # different random weights per rank
+    m = GeneratorModel(core, "FRVSR")
+    m.compile(loss=["mean_squared_error"] * 2, loss_weights=[1., 1.], optimizer=Adam(lr=1e-4))
+    dp.init_if_needed()
+    w0 = list(rn.make_weights(seed=7).items()) if rank == 0 else core.tensors
+    core.set_tensors(dp.broadcast_weights_(w0, 0))                                    # rank 0's weights everywhere
+    a, b, c, hr = _batch(2 * world, 16, 16)
+    sl = slice(2 * rank, 2 * rank + 2)
+    losses = []
+    for _ in range(2):
+        losses.append(m.train_on_batch([a[sl], b[sl], c[sl]], [hr[sl], a[sl]]))
+    out.put((rank, losses, [x.copy() for x in m.get_weights()]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_train_like_one_process_on_the_whole_batch(weights7):
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # one process, whole batch
+    from layers import Adam, GeneratorCore, GeneratorModel
+    core = GeneratorCore((16, 16, 3), dtype="fp32", device=0)
+    core.set_tensors(list(weights7.items()))
+    m = GeneratorModel(core, "FRVSR")
+    m.compile(loss=["mean_squared_error"] * 2, loss_weights=[1., 1.], optimizer=Adam(lr=1e-4))
+    a, b, c, hr = _batch(2 * world, 16, 16)
+    want_l = [m.train_on_batch([a, b, c], [hr, a]) for _ in range(2)]
+    want_w = m.get_weights()
+    for rank, losses, weights in got:
+        assert np.allclose(losses, want_l, rtol=1e-5), (rank, losses, want_l)          # mean of the shard losses = batch loss
+        d = np.concatenate([np.abs(x - y).ravel() for x, y in zip(weights, want_w)])
+        # same gradient up to summation order -> same Adam steps (2 x 1e-4); elements with a gradient at rounding
+        # level may differ by a fraction of a step
+        assert d.mean() <= 0.01 * 2e-4 and np.quantile(d, 0.999) <= 0.5 * 2e-4, (rank, d.mean(), d.max())
+    for x, y in zip(got[0][2], got[1][2]):
+        np.testing.assert_array_equal(x, y)                                            # the ranks stay in lock step exactly
