@@ -606,9 +606,10 @@ hipError_t launch_dgrad_s2_x3(const float* dy, const void* wpack, int nt, int ws
 // One workgroup = 64 consecutive pixels x (cin / 16) waves; a wave owns 16 output channels, so its weights are
 // wave-uniform and come through scalar loads straight into the FMAs (no LDS), a lane owns one pixel and
 // reads the dY taps as one 16-byte load each (the four waves share them in L1).
+template <int COUT>   // compile-time: the wave's 16 x COUT weights of a tap are one contiguous run of scalar loads
 __global__ __launch_bounds__(256) void dgrad_few_kernel(const float* __restrict__ g, const float* __restrict__ w,
                                                         float* __restrict__ dx, const float* __restrict__ y, int act,
-                                                        int B, int H, int W, int cin, int cout, int gcs, int xcs) {
+                                                        int B, int H, int W, int cin, int gcs, int xcs) {
     const int lane = threadIdx.x & 63;
     const int c0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16;
     const long npix = (long)B * H * W;
@@ -624,14 +625,12 @@ __global__ __launch_bounds__(256) void dgrad_few_kernel(const float* __restrict_
         const int sy = yy + 1 - tap / 3, sx = x + 1 - tap % 3;
         const bool in = sy >= 0 && sy < H && sx >= 0 && sx < W;
         const f32x4 u = *reinterpret_cast<const f32x4*>(g + (in ? (p + (1 - tap / 3) * W + (1 - tap % 3)) * gcs : 0));
-        const float* wt = w + ((size_t)tap * cin + c0) * cout;   // wave-uniform: scalar loads
+        const float* wt = w + ((size_t)tap * cin + c0) * COUT;   // wave-uniform: scalar loads
 #pragma unroll
-        for (int co = 0; co < 3; ++co) {
-            if (co < cout) {                                     // uniform
-                const float gv = in ? u[co] : 0.f;
+        for (int co = 0; co < COUT; ++co) {
+            const float gv = in ? u[co] : 0.f;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) acc[c] += gv * wt[c * cout + co];
-            }
+            for (int c = 0; c < 16; ++c) acc[c] += gv * wt[c * COUT + co];
         }
     }
     float* o = dx + p * xcs + c0;
@@ -656,8 +655,10 @@ hipError_t launch_dgrad_few(const float* g, const float* w, float* dx, const flo
     if (cin % 16 || cin > 64 || cout > 3 || cout < 1 || xcs % 4 || gcs % 4 || (y && act != A_RELU && act != A_LRELU))
         return hipErrorInvalidValue;
     const long npix = (long)B * H * W;
-    hipLaunchKernelGGL(dgrad_few_kernel, dim3(blocks_for(npix, 64)), dim3(64 * (cin / 16)), 0, s, g, w, dx, y, act, B, H, W, cin,
-                       cout, gcs, xcs);
+    const dim3 grid(blocks_for(npix, 64)), block(64 * (cin / 16));
+    if (cout == 3) hipLaunchKernelGGL(dgrad_few_kernel<3>, grid, block, 0, s, g, w, dx, y, act, B, H, W, cin, gcs, xcs);
+    else if (cout == 2) hipLaunchKernelGGL(dgrad_few_kernel<2>, grid, block, 0, s, g, w, dx, y, act, B, H, W, cin, gcs, xcs);
+    else hipLaunchKernelGGL(dgrad_few_kernel<1>, grid, block, 0, s, g, w, dx, y, act, B, H, W, cin, gcs, xcs);
     return hipGetLastError();
 }
 
