@@ -149,6 +149,12 @@ int sr_op_warp(int device, int B, int H, int W, int C, const float* img, const f
 /* tf.space_to_depth(x, bs): reference layers.py:109.  out (B,H/bs,W/bs,bs*bs*C). */
 int sr_op_space_to_depth(int device, int B, int H, int W, int C, int bs, const float* x, float* out);
 
+/* LR synthesis of the reference's train / eval drivers (FRVSR.py:117-119, 274-277): cv2.GaussianBlur(hr, (5,5), 0)
+ * (taps [1,4,6,4,1]/16, BORDER_REFLECT_101) followed by cv2.resize to a quarter of the size with INTER_CUBIC
+ * (weights [-3,19,19,-3]/32 on each block of 4), fused into one 8 x 8 gather.  hr (N,H,W,C), H and W multiples
+ * of 4 -> lr (N,H/4,W/4,C).  Host pointers. */
+int sr_op_blur_cubic_downscale(int device, int N, int H, int W, int C, const float* hr, float* lr);
+
 /* ---- training step (SURVEY.md section 8 f, rank 1) ------------------------------------------------
  * Replaces frvsr.train_on_batch([lr_t, lr_tm1, est_tm1], [hr_t, lr_t]) (reference FRVSR.py:154-156)
  * on the model compiled at FRVSR.py:69-71: loss = 1 * mean((I_est_t - hr_t)^2) + 1 * mean((I_LR_est_t_1

@@ -74,6 +74,9 @@ hipError_t launch_srnet_input(const float* lr_t, const float* s_s, void* out, in
 hipError_t launch_warp3(const float* img, const float* flow, float* out, int B, int H, int W, hipStream_t s);
 hipError_t launch_teco_epilogue(float* est, const float* lr_t, int B, int H, int W, hipStream_t s);
 
+// LR synthesis of the reference's drivers: GaussianBlur 5x5 (sigma 0 table, reflect-101) + cubic x1/4, hr [N,H,W,C] -> lr [N,H/4,W/4,C]
+hipError_t launch_blur_cubic_down4(const float* hr, float* lr, int N, int H, int W, int C, hipStream_t s);
+
 // generic fp32 single ops for the per-op C-ABI entry points
 hipError_t launch_pad_channels(const float* in, void* out, int out_bf16, long npix, int C, int Cp, hipStream_t s);
 hipError_t launch_maxpool2_generic(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);

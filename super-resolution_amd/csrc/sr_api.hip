@@ -1003,6 +1003,15 @@ int sr_op_space_to_depth(int device, int B, int H, int W, int C, int bs, const f
     });
 }
 
+int sr_op_blur_cubic_downscale(int device, int N, int H, int W, int C, const float* hr, float* lr) {
+    if (N < 1 || H < 4 || W < 4 || C < 1) return fail(nullptr, SR_ERR_ARG, "non-positive dimension");
+    if (H % 4 || W % 4) return fail(nullptr, SR_ERR_SHAPE, "blur + cubic x1/4: H and W must be multiples of 4");
+    const size_t n_in = (size_t)N * H * W * C;
+    return simple_op(device, n_in, n_in / 16, hr, lr, [&](const float* a, float* o) {
+        return launch_blur_cubic_down4(a, o, N, H, W, C, nullptr);
+    });
+}
+
 int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, int Cin, int Cout, int residual,
                   int iters, float* ms_per_launch) {
     int rc = op_prologue(device);

@@ -52,6 +52,7 @@ SIGNATURES = {
     "sr_op_resize_bilinear": (C.c_int, [C.c_int] * 6 + [_vp, _vp]),
     "sr_op_warp": (C.c_int, [C.c_int] * 5 + [_vp, _vp, _vp]),
     "sr_op_space_to_depth": (C.c_int, [C.c_int] * 6 + [_vp, _vp]),
+    "sr_op_blur_cubic_downscale": (C.c_int, [C.c_int] * 5 + [_vp, _vp]),
     "sr_train_param_count": (C.c_int, [_vp, _i64p]),
     "sr_train_grads": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _f32p]),
     "sr_train_grads_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _f32p]),
@@ -355,6 +356,18 @@ def space_to_depth(x, bs=4, device=0):
         raise ValueError("space_to_depth: H and W must be multiples of the block size")
     out = np.empty((B, H // bs, W // bs, bs * bs * Cc), np.float32)
     _check(lib().sr_op_space_to_depth(device, B, H, W, Cc, bs, _ptr(x), _ptr(out)))
+    return out
+
+
+def blur_cubic_downscale(hr, device=0):
+    """[N,H,W,C] -> [N,H/4,W/4,C]: the reference's GaussianBlur 5x5 + INTER_CUBIC x1/4 LR synthesis on the GPU
+    (same arithmetic as utils.blur_cubic_downscale, one fused pass)."""
+    hr = _f32(hr)
+    N, H, W, Cc = hr.shape
+    if H % 4 or W % 4:
+        raise ValueError("HR height and width must be multiples of 4")
+    out = np.empty((N, H // 4, W // 4, Cc), np.float32)
+    _check(lib().sr_op_blur_cubic_downscale(device, N, H, W, Cc, _ptr(hr), _ptr(out)))
     return out
 
 

@@ -105,7 +105,7 @@ def test_train_stage_runs_the_reference_loop(tmp_path, weights7):
     lr = utils.blur_cubic_downscale(hr[1])
     want = rt.run_clip(weights7, lr[:, None])                                 # clip 1 through the oracle
     assert not x[1][3].any() and not x[2][3].any()                           # frame 0: zero state (FRVSR.py:124-125)
-    assert np.array_equal(x[1][4], lr[0]) and np.abs(x[2][5] - want[1, 0]).max() <= 1e-3
+    assert np.abs(x[1][4] - lr[0]).max() <= 2e-6 and np.abs(x[2][5] - want[1, 0]).max() <= 1e-3   # LR synthesis runs on the GPU
     new_w, want_l = ref_train.train_on_batch(dict(weights7), ref_train.KerasAdam(1e-4), x[0], x[1], x[2], y[0])
     loss = m.frvsr.train_on_batch(x, y)
     assert np.allclose(loss, want_l, rtol=1e-4)

@@ -217,3 +217,19 @@ def test_error_paths(sh):
     with pytest.raises(ValueError):   # weights not loaded
         ctx.step(np.zeros((1, 16, 16, 3)), np.zeros((1, 16, 16, 3)), np.zeros((1, 64, 64, 3)))
     ctx.close()
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 16, 24, 3), (1, 4, 4, 3), (3, 64, 64, 3), (1, 8, 12, 1), (1, 256, 256, 3)])
+def test_blur_cubic_downscale(sh, N, H, W, C):
+    """LR synthesis of the reference's drivers (FRVSR.py:117-119, 274-277) as one fused gather against the numpy
+    restatement (two blur passes, two cubic passes): same taps, different summation order -> 2e-6."""
+    import utils
+    hr = rnd(21, N, H, W, C, lo=0.0, hi=1.0)
+    got = sh.blur_cubic_downscale(hr)
+    want = utils.blur_cubic_downscale(hr)
+    assert got.shape == (N, H // 4, W // 4, C)
+    assert np.abs(got - want).max() <= 2e-6
+    const = np.full((1, 8, 8, 3), 0.37, np.float32)              # weights sum to one, borders reflect
+    assert np.abs(sh.blur_cubic_downscale(const) - 0.37).max() <= 1e-6
+    with pytest.raises(ValueError):
+        sh.blur_cubic_downscale(np.zeros((1, 6, 8, 3), np.float32))
