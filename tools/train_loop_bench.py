@@ -1,0 +1,63 @@
+"""Times whole iterations of stage.train through the facade (reference FRVSR.py:100-200, config 4: batch_size 4 clips
+x c_frames 10 frames of 256x256 HR / 64x64 LR): clip sampling, LR synthesis, the no-gradient recurrence that
+makes the previous estimates, train_on_batch.  Synthetic .npy clips in a temporary directory.
+
+    python tools/train_loop_bench.py [--iters 20] [--dtype bf16x3]
+"""
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "super-resolution_amd"))
+from FRVSR import FrameRecurrentVideoSR  # noqa: E402
+import utils  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16x3")
+    a = ap.parse_args()
+    tmp = tempfile.mkdtemp(prefix="sr_train_")
+    os.makedirs(os.path.join(tmp, "clips"))
+    rng = np.random.default_rng(0)
+    for k in range(3):
+        np.save(os.path.join(tmp, "clips", f"{k}.npy"), rng.integers(0, 256, (24, 288, 288, 3), dtype=np.uint8))
+    cfg = {"root_dir": tmp, "dtype": a.dtype,
+           "data": {"low_res": 64, "high_res": 256, "channels": 3, "upscale": 4, "videos": os.path.join(tmp, "clips"), "rows": 1, "cols": 1},
+           "cnn": {"model": "frvsr", "pretrained_model": None},
+           "train": {"iterations": 0, "batch_size": 4, "c_frames": 10, "sample_freq": 10 ** 9, "checkpoint_freq": 10 ** 9,
+                     "info_freq": 10 ** 9, "seed": 1}}
+    m = FrameRecurrentVideoSR((64, 64, 3), (256, 256, 3), tmp, cfg)
+    m.build()
+    clips = [utils.load_clip(p) for p in utils.get_videos(cfg)]
+    r = np.random.RandomState(0)
+    t = {"sample": 0.0, "batch": 0.0, "step": 0.0}
+    for it in range(a.iters + 2):
+        if it == 2:
+            t = dict.fromkeys(t, 0.0)
+            t0 = time.perf_counter()
+        s0 = time.perf_counter()
+        hr = np.stack([utils.normalize(utils.get_frames(clips[j], cfg, r)) for j in r.randint(0, len(clips), size=4)])
+        s1 = time.perf_counter()
+        x, y = m.make_train_batch(hr)
+        s2 = time.perf_counter()
+        loss = m.frvsr.train_on_batch(x, y)
+        s3 = time.perf_counter()
+        t["sample"] += s1 - s0
+        t["batch"] += s2 - s1
+        t["step"] += s3 - s2
+    dt = (time.perf_counter() - t0) / a.iters
+    print(f"stage.train iteration (4 clips x 10 frames, {a.dtype}): {dt * 1e3:.1f} ms = {40 / dt:.0f} samples/s; "
+          f"clip sampling + normalize {t['sample'] / a.iters * 1e3:.1f} ms, LR synthesis + recurrence {t['batch'] / a.iters * 1e3:.1f} ms, "
+          f"train_on_batch {t['step'] / a.iters * 1e3:.1f} ms; loss {loss[0]:.4f}")
+
+
+if __name__ == "__main__":
+    main()
