@@ -2,15 +2,20 @@
 // MSE losses and Adam), gfx950.  All tensors are fp32 NHWC with explicit channel strides.
 //
 //   wgrad         kernel + bias gradient of Conv2D 3x3 / Conv2DTranspose 3x3 s2: a GEMM whose K dimension
-//                 is the PIXELS (v_mfma_f32_32x32x2_f32, two pixels per MFMA), so both operands are read
-//                 straight from the NHWC tensors, 32 consecutive channels of one pixel per half wave
-//                 (full 128-B lines, no staging); one wave owns a 32 x 32 block of (cin, cout) for all
-//                 9 taps (144 accumulator registers), slices of the pixel range go to different
-//                 workgroups and a second kernel sums the slices in a fixed order (deterministic).
+//                 is the PIXELS, so both operands are read straight from the NHWC tensors, 32 consecutive
+//                 channels of one pixel per half wave (full 128-B lines, no staging, no transpose); one wave
+//                 owns a 32 x 32 block of (cin, cout) for all 9 taps (144 accumulator registers).
+//                 wgrad_x3_kernel (ctx bf16x3): v_mfma_f32_32x32x16_bf16, 16 pixels of a row per MFMA, operands
+//                 split hi + lo once per row window; wgrad_kernel (ctx fp32): v_mfma_f32_32x32x2_f32; mode 2
+//                 folds the taps of a <= 3-output conv into N.  Slices of the pixel range go to different
+//                 waves, the four waves of a workgroup add up through LDS, a second kernel sums the
+//                 partials in a fixed order (deterministic).
 //   dgrad_s2      data gradient of Conv2DTranspose s2 = 3x3 stride-2 convolution of dY with the same
-//                 kernel; pixels are the M dimension, each lane streams 32 contiguous channels of its
-//                 pixel (one 128-B line) per tap, weights come from the Keras-layout tensor through L1.
-//   (the data gradient of the stride-1 convolutions runs on the forward MFMA kernel of conv_mfma.hip
+//                 kernel; pixels are the M dimension, each lane streams contiguous channels of its pixel
+//                 per tap; bf16x3 variant on forward-packed hi / lo weight fragments, fp32 variant on the
+//                 Keras-layout tensor through L1; the producer's ReLU mask is folded into the store.
+//   dgrad_few     data gradient of the convs with <= 3 outputs (HBM bound), activation mask in the store
+//   (the data gradient of the other stride-1 convolutions runs on the forward MFMA kernel of conv_mfma.hip
 //    with mirrored, transposed weights: sr_api.hip pack_entries PK_DGRAD)
 //   act_bwd, maxpool2_bwd, resize_bwd, warp_bwd_flow, hr_warp_bwd, mse_grad: HBM-bound gathers
 //   adam, repack  optimizer update on the flat parameter vector and the re-pack of the updated

@@ -7,6 +7,8 @@ relative to each tensor's max-abs gradient in fp32 (measured <= 2e-6) on inputs 
 well conditioned (conditioned_data below), 1e-2 in bf16x3 (kink-flip noise, explained there), losses to
 1e-5 relative; two Adam steps move the weights like Keras 2.2.4's Adam to within 2 % of the step size.  Parity is unpinned by the
 reference itself (no Keras / TF here), exactly as for the forward path."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -282,3 +284,34 @@ def test_training_is_refused_where_it_cannot_run(sh, weights7):
     with pytest.raises(ValueError):                       # batch > max_batch
         ctx.train_grads(*step_data(1, 2, 16, 16))
     ctx.close()
+
+
+def test_device_pointer_entry_points(sh, weights7):
+    """sr_train_grads_dev / the d_grads output buffer / sr_train_apply(d_grads, grad_scale): what a data-parallel
+    job uses (torch CUDA tensors are only the memory; gradients come from and go back into libsr_hip)."""
+    B, h, w = 2, 16, 16
+    data = step_data(900, B, h, w)
+    ctx = sh.Context(h, w, max_batch=B, dtype="fp32")
+    ctx.load_weights(weights7)
+    losses, want = ctx.train_grads(*data, read=True)
+    dev = [torch.from_numpy(a).cuda() for a in data]
+    gbuf = torch.zeros(ctx.param_count(), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    out = (C.c_float * 3)()
+    rc = sh.lib().sr_train_grads_dev(ctx._h, B, *[C.c_void_p(t.data_ptr()) for t in dev], C.c_void_p(gbuf.data_ptr()), out)
+    assert rc == 0, sh._err(ctx._h)
+    assert np.allclose(list(out), losses, rtol=1e-6)
+    assert np.array_equal(gbuf.cpu().numpy(), want)                # same kernels, same order: bit identical
+    # Adam from an external buffer scaled by 1/2 == Adam from the ctx's own gradient on half the loss scale:
+    # the first Adam step is lr * sign(g) whatever the scale, so both contexts move alike
+    ctx2 = sh.Context(h, w, max_batch=B, dtype="fp32")
+    ctx2.load_weights(weights7)
+    ctx2.train_grads(*data)
+    ctx2.train_apply(lr=1e-4)
+    gbuf *= 2.0
+    torch.cuda.synchronize()
+    ctx.train_apply(d_grads=gbuf.data_ptr(), grad_scale=0.5, lr=1e-4)
+    for (n, a), (_, b) in zip(ctx.get_weights(), ctx2.get_weights()):
+        np.testing.assert_array_equal(a, b)
+    ctx.close()
+    ctx2.close()
