@@ -86,7 +86,8 @@ class FrameRecurrentVideoSR(object):
         lr = sr_hip.blur_cubic_downscale(hr_batch.reshape((n * c,) + hr_batch.shape[2:]), device=self.core.device)
         lr = lr.reshape((n, c) + lr.shape[1:])                                   # [n, c, h, w, 3]
         gen = self._generator()
-        prev_est = np.zeros((n, c) + self.hr_shape, np.float32)
+        prev_est = np.empty((n, c) + self.hr_shape, np.float32)
+        prev_est[:, 0] = 0.0                                                     # frame 0: zero state (FRVSR.py:124-125)
         gen.clip_begin(n)
         for f in range(c - 1):
             prev_est[:, f + 1] = gen.clip_push(lr[:, f])
