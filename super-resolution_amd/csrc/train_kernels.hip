@@ -69,13 +69,13 @@ static WgradPlan wgrad_plan(int B, int H, int W, int cin, int cout, int convt, i
         if (ns > nseg / 2) ns = nseg / 2;         // at least two 16-pixel segments per slice
     }
     if (ns < 1) ns = 1;
-    // 9-tap kernels: the four waves of a workgroup take four consecutive slices of ONE block and add their
+    // the four waves of a workgroup take four consecutive slices of ONE block and add their
     // accumulators through LDS before writing, so a launch leaves a quarter of the partials to reduce
-    p.nslices = p.mode == WG_TAPSN ? (int)ns : (int)((ns + 3) / 4);
+    p.nslices = (int)((ns + 3) / 4);
     return p;
 }
 
-// workgroup -> (block, slice group) for the 9-tap kernels: workgroup ids go round-robin over the 8 XCDs, so the
+// workgroup -> (block, slice group): workgroup ids go round-robin over the 8 XCDs, so the
 // XCD index is kept in the slice group and the blocks of one group (which read the same pixels) share an L2
 struct WgId {
     int blk, grp;
@@ -125,22 +125,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
     constexpr int NT = MODE == WG_TAPSN ? 1 : 9;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, kh = lane >> 5;
-    __shared__ float red[MODE == WG_TAPSN ? 1 : 9 * 1024 + 64];
-    int blk, slice, wslice, nws;
-    if constexpr (MODE == WG_TAPSN) {
-        const int gw = blockIdx.x * 4 + wave;
-        blk = gw % pl.nblk;
-        slice = wslice = gw / pl.nblk;
-        nws = pl.nslices;
-        if (slice >= pl.nslices) return;   // no barrier on this path
-    } else {
-        const WgId id = wg_decode(pl);
-        blk = id.blk;
-        slice = id.grp;
-        if (slice >= pl.nslices) return;   // uniform for the workgroup
-        wslice = slice * 4 + wave;
-        nws = pl.nslices * 4;
-    }
+    __shared__ float red[NT * 1024 + 64];
+    const WgId id = wg_decode(pl);
+    const int blk = id.blk, slice = id.grp;
+    if (slice >= pl.nslices) return;   // uniform for the workgroup
+    const int wslice = slice * 4 + wave, nws = pl.nslices * 4;
     const int rb = blk / pl.ncolb, cb = blk - rb * pl.ncolb;
     const int H = a.H, W = a.W;
     const unsigned npix = (unsigned)a.B * H * W;
@@ -219,33 +208,44 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
             if (++y == H) y = 0;
         }
     };
-    float av[NT], bv = 0.f;
+    // k-steps go in groups of U: the next group's loads are in flight during this group's MFMAs.  The light
+    // taps-in-N waves (one MFMA per k-step) are bound by load latency, so they keep four k-steps ahead.
+    constexpr int U = MODE == WG_TAPSN ? 4 : 1;
+    float av[U][NT], bv[U];
+    auto load_group = [&](float (&A)[U][NT], float (&Bv)[U], unsigned q) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) av[t] = 0.f;
-    if (q0 < q1) fetch(av, bv);
-    for (unsigned q = q0; q < q1; ++q) {
-        float an[NT], bn;
-        advance();
-        fetch(an, bn);   // next k-step's operands (all-masked past the end) are in flight during this one's MFMAs
-        if (q + 1 >= q1) {
-            bn = 0.f;
+        for (int u = 0; u < U; ++u) {
+            fetch(A[u], Bv[u]);
+            if (q + u >= q1) {   // past this wave's slice (the pixels belong to the next one, or lie past the end)
+                Bv[u] = 0.f;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) an[t] = 0.f;
+                for (int t = 0; t < NT; ++t) A[u][t] = 0.f;
+            }
+            advance();
         }
-        // bias: conv sums dY (the centre-tap columns in taps-in-N); transposed conv: the four phases
-        // (taps 0, 1, 3, 4) cover every output pixel once
-        if constexpr (MODE == WG_CONVT) bsum += av[0] + av[1] + av[3] + av[4];
-        else bsum += bv;
+    };
+    load_group(av, bv, q0);
+    for (unsigned q = q0; q < q1; q += U) {
+        float an[U][NT], bn[U];
+        load_group(an, bn, q + U);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
+        for (int u = 0; u < U; ++u) {
+            // bias: conv sums dY (the centre-tap columns in taps-in-N); transposed conv: the four phases
+            // (taps 0, 1, 3, 4) cover every output pixel once
+            if constexpr (MODE == WG_CONVT) bsum += av[u][0] + av[u][1] + av[u][3] + av[u][4];
+            else bsum += bv[u];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) av[t] = an[t];
-        bv = bn;
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][t], bv[u], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) av[u][t] = an[u][t];
+            bv[u] = bn[u];
+        }
     }
-    if constexpr (MODE != WG_TAPSN) {
-        wg_combine<NT>(acc, bsum, wave, lane, red);
-        if (wave != 0) return;
-    }
+    wg_combine<NT>(acc, bsum, wave, lane, red);
+    if (wave != 0) return;
     float* out = a.part + ((size_t)slice * pl.nblk + blk) * pl.part;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
     const WgradPlan pl = wgrad_plan(a.B, a.H, a.W, a.cin, a.cout, a.convt, a.x3);
-    const dim3 grid(pl.mode == WG_TAPSN ? (pl.nblk * pl.nslices + 3) / 4 : wg_grid(pl)), block(256);
+    const dim3 grid(wg_grid(pl)), block(256);
     if (pl.x3 && pl.mode == WG_CONVT)
         hipLaunchKernelGGL(wgrad_x3_kernel<WG_CONVT>, grid, block, 0, s, a, pl);
     else if (pl.x3)
