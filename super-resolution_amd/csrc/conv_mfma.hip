@@ -492,7 +492,32 @@ struct EpiLds {
     static constexpr int WAVE_BYTES = 64 * ROW;
 };
 
-template <class G, int NT, typename OT, bool ADD_BIAS = true>
+// What the epilogue does with the tensor behind ConvArgs::res.  Inference adds it (residual); the
+// training data-gradient (MASK) treats it as the stored output y of the producing activation and
+// scales the gradient by that activation's derivative: 1 where y > 0, `neg` elsewhere.
+template <typename OT, bool MASK>
+__device__ __forceinline__ u32x4 merge_res(u32x4 val, u32x4 rr, float neg) {
+    if constexpr (sizeof(OT) == 4) {
+        f32x4 x = __builtin_bit_cast(f32x4, val), y = __builtin_bit_cast(f32x4, rr);
+        if constexpr (MASK) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = y[j] > 0.f ? x[j] : neg * x[j];
+        } else {
+            x += y;
+        }
+        return __builtin_bit_cast(u32x4, x);
+    } else {
+        bf16x8 x = __builtin_bit_cast(bf16x8, val), y = __builtin_bit_cast(bf16x8, rr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (MASK) x[j] = (float)y[j] > 0.f ? x[j] : (__bf16)(neg * (float)x[j]);
+            else x[j] = (__bf16)((float)x[j] + (float)y[j]);
+        }
+        return __builtin_bit_cast(u32x4, x);
+    }
+}
+
+template <class G, int NT, typename OT, bool ADD_BIAS = true, bool MASK = false>
 __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[G::MT][NT], const ConvArgs& a, int b, int y0, int x0,
                                              int wave, int lane, unsigned char* smem) {
     using E = EpiLds<G, NT, OT>;
@@ -500,8 +525,10 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[G::MT][NT], con
     const int r = lane & 31, h = lane >> 5;
     const int H = a.H, W = a.W;
     const int act = a.act;
-    const float slope = (act == A_RELU || act == A_CLIP01) ? 0.f : (act == A_LRELU ? 0.2f : 1.f);
-    const float hi = act == A_CLIP01 ? 1.f : INFINITY;
+    // MASK: a.act names the activation whose derivative scales the result, the conv itself has none
+    const float neg = act == A_LRELU ? 0.2f : 0.f;
+    const float slope = MASK ? 1.f : ((act == A_RELU || act == A_CLIP01) ? 0.f : (act == A_LRELU ? 0.2f : 1.f));
+    const float hi = (!MASK && act == A_CLIP01) ? 1.f : INFINITY;
     unsigned char* sc = smem + wave * E::WAVE_BYTES;
     const int cbase = blockIdx.y * NT * 32;
     // row/column of this lane in the transposed phase
@@ -563,16 +590,7 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[G::MT][NT], con
         if (ok) {
             if (resp) {
                 const u32x4 rr = *reinterpret_cast<const u32x4*>(resp + opix * pxs_r);
-                if constexpr (sizeof(OT) == 4) {
-                    f32x4 x = __builtin_bit_cast(f32x4, val), y = __builtin_bit_cast(f32x4, rr);
-                    x += y;
-                    val = __builtin_bit_cast(u32x4, x);
-                } else {
-                    bf16x8 x = __builtin_bit_cast(bf16x8, val), y = __builtin_bit_cast(bf16x8, rr);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = (__bf16)((float)x[j] + (float)y[j]);
-                    val = __builtin_bit_cast(u32x4, x);
-                }
+                val = merge_res<OT, MASK>(val, rr, neg);
             }
             *reinterpret_cast<u32x4*>(outp + opix * pxs_o) = val;
         }
@@ -653,7 +671,7 @@ __device__ __forceinline__ void stage_store_p(const u32x4 (&regs)[G::ITER], unsi
 // Fast epilogue for interior tiles whose channel block is stored whole: the accumulators already
 // hold the bias (they start from it), the activation is max(t, slope*t), and every address is a
 // uniform base plus one per-lane offset computed once.
-template <class G, int NT, typename OT>
+template <class G, int NT, typename OT, bool MASK = false>
 __device__ __forceinline__ void epilogue_lds_fast(const f32x16 (&acc)[G::MT][NT], const ConvArgs& a, int b, int y0, int x0,
                                                   int wave, int lane, unsigned char* smem, unsigned long long (&es)[4], bool stamp) {
     using E = EpiLds<G, NT, OT>;
@@ -662,7 +680,8 @@ __device__ __forceinline__ void epilogue_lds_fast(const f32x16 (&acc)[G::MT][NT]
     const int r = lane & 31, h = lane >> 5;
     // one uniform multiplier instead of a per-element choice of activation (which compiles to a scalar
     // compare-and-branch per accumulator register: 1600 instructions for these 16 LDS stores)
-    const float slope = a.act == A_RELU ? 0.f : (a.act == A_LRELU ? 0.2f : 1.f);
+    const float neg = a.act == A_LRELU ? 0.2f : 0.f;   // MASK: derivative of a.act where its output is not positive
+    const float slope = MASK ? 1.f : (a.act == A_RELU ? 0.f : (a.act == A_LRELU ? 0.2f : 1.f));
     unsigned char* sc = smem + wave * E::WAVE_BYTES;
     const int prow = lane / E::LPR, chunk = lane % E::LPR;
     const int co = blockIdx.y * NT * 32 + chunk * (16 / SZ);
@@ -722,18 +741,7 @@ __device__ __forceinline__ void epilogue_lds_fast(const f32x16 (&acc)[G::MT][NT]
             const int prel = ((k * E::RPI) >> 5) * a.W + ((k * E::RPI) & 31);              // uniform
             u32x4 val = *reinterpret_cast<const u32x4*>(rd + k * E::RPI * E::ROW);
             if (k == 1 && stamp) { unsigned long long e1 = __builtin_readcyclecounter(); es[2] += e1 - e0; e0 = e1; }
-            if (rb) {
-                if constexpr (SZ == 4) {
-                    f32x4 x = __builtin_bit_cast(f32x4, val), y = __builtin_bit_cast(f32x4, rr[k]);
-                    x += y;
-                    val = __builtin_bit_cast(u32x4, x);
-                } else {
-                    bf16x8 x = __builtin_bit_cast(bf16x8, val), y = __builtin_bit_cast(bf16x8, rr[k]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = (__bf16)((float)x[j] + (float)y[j]);
-                    val = __builtin_bit_cast(u32x4, x);
-                }
-            }
+            if (rb) val = merge_res<OT, MASK>(val, rr[k], neg);
             *reinterpret_cast<u32x4*>(ob + (size_t)prel * pxs_o + vo_out) = val;
         }
         if (stamp) { unsigned long long e1 = __builtin_readcyclecounter(); es[3] += e1 - e0; e0 = e1; }
@@ -745,7 +753,7 @@ __device__ __forceinline__ void epilogue_lds_fast(const f32x16 (&acc)[G::MT][NT]
 // 32-channel N blocks) sit in LDS next to the halo tile, copied once per workgroup instead of being
 // streamed through the vector L1 by each of the 4 waves, so the MFMA loop issues only LDS reads.
 // The next chunk (halo tile + weights) is fetched into registers while the current one computes.
-template <int PREC, int NT, int STEPS, bool PL>
+template <int PREC, int NT, int STEPS, bool PL, bool MASK = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
     using G = Geo<PREC, M_CONV, NT, STEPS>;
     constexpr int NSEG = 9 * STEPS;
@@ -952,11 +960,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
                 const bool interior = cur.y0 + G::TH <= H && cur.x0 + TW <= W &&
                                       (int)(blockIdx.y + 1) * NT * 32 <= a.cout_store && a.act != A_CLIP01;
                 if (interior) {
-                    if (a.out_f32) epilogue_lds_fast<G, NT, float>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem, es, stamp);
-                    else epilogue_lds_fast<G, NT, __bf16>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem, es, stamp);
+                    if (a.out_f32) epilogue_lds_fast<G, NT, float, MASK>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem, es, stamp);
+                    else epilogue_lds_fast<G, NT, __bf16, MASK>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem, es, stamp);
                 } else {
-                    if (a.out_f32) epilogue_lds<G, NT, float, false>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem);
-                    else epilogue_lds<G, NT, __bf16, false>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem);
+                    if (a.out_f32) epilogue_lds<G, NT, float, false, MASK>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem);
+                    else epilogue_lds<G, NT, __bf16, false, MASK>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem);
                 }
             }
         } else {
@@ -1145,6 +1153,19 @@ static hipError_t launch_k(K kernel, size_t lds, ConvArgs a, int th, int ncb, hi
 template <int PREC, int MODE, int NT, int STEPS>
 static hipError_t launch_one(const ConvArgs& a, int ncb, hipStream_t s) {
     static bool attr_done = false;
+    if (a.res_mask) {
+        // the masked epilogue exists only on the LDS-transpose path of the fp32 / bf16x3 conv kernels
+        if constexpr (MODE == M_CONV && PREC != P_BF16) {
+            const bool ok = a.res && (a.act == A_RELU || a.act == A_LRELU) && a.cout_store % 8 == 0 &&
+                            a.out_cs % 8 == 0 && a.res_cs % 8 == 0 && !(a.dbg & 8);
+            if (!ok) return hipErrorInvalidValue;
+            static bool attr_mask = false;
+            return launch_k(&conv3x3_lds_kernel<PREC, NT, STEPS, true, true>, conv_lds_bytes(PREC, MODE, NT, STEPS, 2),
+                            a, 8, ncb, s, attr_mask, 2);
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if constexpr (MODE == M_CONV) {
         return launch_k(&conv3x3_lds_kernel<PREC, NT, STEPS, true>, conv_lds_bytes(PREC, MODE, NT, STEPS, 2), a, 8,
                         ncb, s, attr_done, 2);

@@ -41,6 +41,10 @@ struct ConvArgs {
     const void* proj_w;
     int dbg;               // ablation switches for tools/conv_bench.py (0 in production)
     unsigned long long* stamps;   // diagnostic build only (dbg & 64): per-phase cycle sums, else nullptr
+    // training data-gradient: res is not a residual but the stored output y of the activation `act`
+    // that produced this conv's gradient target; out = conv(in) * act'(y) (1 where y > 0, else 0 / 0.2),
+    // no bias activation of its own.  M_CONV, fp32 / bf16x3, vector-aligned strides only.
+    int res_mask;
 };
 
 // steps per chunk / chunk geometry, shared by the packer and the kernel
@@ -108,8 +112,10 @@ hipError_t launch_dgrad_s2_x3(const float* dy, const void* wpack, int nt, int ws
 hipError_t launch_dgrad_few(const float* g, const float* w, float* dx, const float* y, int act, int B, int H, int W, int cin,
                             int cout, int gcs, int xcs, hipStream_t s);
 hipError_t launch_act_bwd(float* g, const float* y, int act, long npix, int C, int gcs, int ycs, hipStream_t s);
-hipError_t launch_maxpool2_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, hipStream_t s);
-hipError_t launch_resize_bwd(const float* gy, float* gx, int B, int H, int W, int C, int sc, int ocs, int accumulate, hipStream_t s);
+// act / (ym, act): optional ReLU / LeakyReLU derivative of the tensor the gradient lands on, folded into the store
+hipError_t launch_maxpool2_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int act, hipStream_t s);
+hipError_t launch_resize_bwd(const float* gy, float* gx, int B, int H, int W, int C, int sc, int ocs, int accumulate,
+                             const float* ym, int act, hipStream_t s);
 hipError_t launch_warp_bwd_flow(const float* img, const float* flow, const float* g, float* gflow, int B, int H, int W,
                                 int C, int gfs, int accumulate, hipStream_t s);
 hipError_t launch_hr_warp_bwd(const float* est_prev, const float* flow, const float* g_sin, float* g_fhr, int B, int H, int W,

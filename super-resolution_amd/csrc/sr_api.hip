@@ -279,6 +279,10 @@ int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, con
     a.in_planar = io.in_planar;
     a.out_planar = io.out_planar;
     a.proj_w = io.proj_w;
+    a.res_mask = io.res_mask;
+    if (io.res_mask && (L.tapsn || L.mode != M_CONV || prec == P_BF16 || !io.res || io.out_planar || io.proj_w ||
+                        (io.act != A_RELU && io.act != A_LRELU) || io.cout_store % 8 || io.out_cs % 8 || io.res_cs % 8))
+        return fail(c, SR_ERR_ARG, "%s: masked data-gradient needs an fp32/bf16x3 3x3 conv with vector-aligned strides", name);
     if (io.proj_w && (L.mode != M_CONVT || L.cout != 64 || L.nt != 2 || !io.out_f32 || io.res))
         return fail(c, SR_ERR_ARG, "%s: tap projection needs a 64-channel transposed conv", name);
     if (io.in_planar && (L.tapsn || L.steps != prec_maxsteps(prec, L.mode) || (L.mode == M_CONVT && L.nchunk != 1)))

@@ -156,6 +156,7 @@ struct ConvIO {
     int act;
     int in_planar = 0, out_planar = 0;   // kernels.h: planes of 64 B per pixel
     const void* proj_w = nullptr;        // transposed conv: fused tap projection, out = P [B,2H,2W,32] fp32
+    int res_mask = 0;                    // kernels.h ConvArgs::res_mask: res is the activation output to mask by
 };
 
 int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, const ConvIO& io, const char* name);

@@ -164,6 +164,13 @@ struct Tape {
              const float* res, const char* name) {
         return run_conv(c, P, st, L, B, {in, H, W, out, out_cs, cout_store, 1, res, out_cs, act}, name);
     }
+    // data gradient with the derivative of the ReLU / LeakyReLU `act` that produced y folded into the store
+    int conv_masked(const ConvLayer& L, const float* in, int H, int W, float* out, int out_cs, int cout_store, int act,
+                    const float* y, const char* name) {
+        ConvIO io{in, H, W, out, out_cs, cout_store, 1, y, out_cs, act};
+        io.res_mask = 1;
+        return run_conv(c, P, st, L, B, io, name);
+    }
     // kernel + bias gradient of tensor pair `ti` (index of the kernel in file order)
     int wgrad(int ti, int mode, int cin, int cout, const float* x, int xcs, const float* dy, int ycs, int H, int W) {
         WgradArgs wa;
@@ -308,8 +315,7 @@ int train_backward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const fl
         snprintf(yn, sizeof yn, "y%d_", r);
         const int l2 = 2 + 2 * r, l1 = 1 + 2 * r;
         RC(t.wgrad(so + 2 * l2, M_CONV, 64, 64, t.a(yn), 64, cur, 64, H, W));
-        RC(t.conv(SD[l2], cur, H, W, oth, 64, 64, A_NONE, nullptr, "train.dgrad"));
-        RC(t.mask(oth, t.a(yn), A_RELU, L0, 64, 64, 64));
+        RC(t.conv_masked(SD[l2], cur, H, W, oth, 64, 64, A_RELU, t.a(yn), "train.dgrad"));
         RC(t.wgrad(so + 2 * l1, M_CONV, 64, 64, t.a(xn), 64, oth, 64, H, W));
         RC(t.conv(SD[l1], oth, H, W, cur, 64, 64, A_NONE, cur, "train.dgrad"));   // g_x += dgrad, in place like the forward
     }
@@ -322,29 +328,34 @@ int train_backward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const fl
         ProfScope ps(c, "train.warp_bwd", 0, (double)L0 * 16 * (12 + 12 + 8) + (double)L0 * 256);
         LAUNCHCHK(c, "hr_warp_bwd", launch_hr_warp_bwd(d_est_prev, d_flow, cur, t.a("g_fhr"), B, H, W, 64, st));
         HIPCHK(c, hipMemsetAsync(t.a("g_flow"), 0, (size_t)L0 * 16 * 4, st));
-        LAUNCHCHK(c, "resize_bwd", launch_resize_bwd(t.a("g_fhr"), t.a("g_flow"), B, H, W, 2, 4, 16, 0, st));
+        LAUNCHCHK(c, "resize_bwd", launch_resize_bwd(t.a("g_fhr"), t.a("g_flow"), B, H, W, 2, 4, 16, 0, nullptr, A_NONE, st));
         LAUNCHCHK(c, "mse", launch_mse_grad(d_lr_warp, d_lr_t, t.a("g_lw"), T->mse_part, T->d_loss + 1, L0, 3, 3, nullptr, 0, st));
         LAUNCHCHK(c, "warp_bwd_flow", launch_warp_bwd_flow(d_lr_tm1, d_flow, t.a("g_lw"), t.a("g_flow"), B, H, W, 3, 16, 1, st));
     }
     RC(t.mask(t.a("g_flow"), d_flow, A_TANH, L0, 2, 16, 2));
     // ---- FNet, reverse order (reference layers.py:27-45)
     const ConvLayer* FD = T->fnet_dg;
+    // every gradient below leaves its kernel already multiplied by the LeakyReLU derivative of the tensor it
+    // lands on (x is a LeakyReLU output in all three helpers), so no separate mask pass runs in FNet
     auto pool_bwd = [&](const char* x, int h, int w, int C) -> int {   // gradient of x's 2x2 pooled output in cur -> oth
         ProfScope ps(c, "train.pool_bwd", 0, (double)B * h * w * C * 4 * 2.25);
-        LAUNCHCHK(c, "maxpool2_bwd", launch_maxpool2_bwd(t.a(x), cur, oth, B, h, w, C, st));
+        LAUNCHCHK(c, "maxpool2_bwd", launch_maxpool2_bwd(t.a(x), cur, oth, B, h, w, C, A_LRELU, st));
         return SR_OK;
     };
-    auto resize_bwd = [&](int h, int w, int C) -> int {   // cur [B,2h,2w,C] -> oth [B,h,w,C]
-        ProfScope ps(c, "train.resize_bwd", 0, (double)B * h * w * C * 4 * 5.0);
-        LAUNCHCHK(c, "resize_bwd", launch_resize_bwd(cur, oth, B, h, w, C, 2, C, 0, st));
+    auto resize_bwd = [&](const char* x, int h, int w, int C) -> int {   // cur [B,2h,2w,C] -> oth [B,h,w,C] = d/dx
+        ProfScope ps(c, "train.resize_bwd", 0, (double)B * h * w * C * 4 * 6.0);
+        LAUNCHCHK(c, "resize_bwd", launch_resize_bwd(cur, oth, B, h, w, C, 2, C, 0, t.a(x), A_LRELU, st));
         return SR_OK;
     };
-    // one conv layer: cur = dL/d(out) with the activation mask already applied
-    auto conv_bwd = [&](int i, const char* x, int xcs, const float* dy, int ycs, int h, int w, float* dx) -> int {
+    // one conv layer: dy = dL/d(out) with the activation mask already applied; x_is_act: the layer's input is a
+    // LeakyReLU output (not a pooled / resized tensor), so its derivative goes into the data-gradient's store
+    auto conv_bwd = [&](int i, const char* x, int xcs, const float* dy, int ycs, int h, int w, float* dx,
+                        bool x_is_act = false) -> int {
         const int cin = FNET_SPEC[i][0], cout = FNET_SPEC[i][1];
         RC(t.wgrad(2 * i, M_CONV, cin, cout, t.a(x), xcs, dy, ycs, h, w));
-        if (dx) RC(t.conv(FD[i], dy, h, w, dx, cin, cin, A_NONE, nullptr, "train.dgrad"));
-        return SR_OK;
+        if (!dx) return SR_OK;
+        if (x_is_act) return t.conv_masked(FD[i], dy, h, w, dx, cin, cin, A_LRELU, t.a(x), "train.dgrad");
+        return t.conv(FD[i], dy, h, w, dx, cin, cin, A_NONE, nullptr, "train.dgrad");
     };
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8;
     RC(conv_bwd(13, "c13", 32, t.a("g_flow"), 16, H, W, nullptr));
@@ -354,52 +365,40 @@ int train_backward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const fl
     }
     RC(conv_bwd(12, "u0", 64, cur, 32, H, W, oth));
     swap();
-    RC(resize_bwd(H1, W1, 64));
+    RC(resize_bwd("d1b", H1, W1, 64));
     swap();
-    RC(t.mask(cur, t.a("d1b"), A_LRELU, L0 / 4, 64, 64, 64));
-    RC(conv_bwd(11, "d1a", 64, cur, 64, H1, W1, oth));
+    RC(conv_bwd(11, "d1a", 64, cur, 64, H1, W1, oth, true));
     swap();
-    RC(t.mask(cur, t.a("d1a"), A_LRELU, L0 / 4, 64, 64, 64));
     RC(conv_bwd(10, "u1", 128, cur, 64, H1, W1, oth));
     swap();
-    RC(resize_bwd(H2, W2, 128));
+    RC(resize_bwd("d2b", H2, W2, 128));
     swap();
-    RC(t.mask(cur, t.a("d2b"), A_LRELU, L0 / 16, 128, 128, 128));
-    RC(conv_bwd(9, "d2a", 128, cur, 128, H2, W2, oth));
+    RC(conv_bwd(9, "d2a", 128, cur, 128, H2, W2, oth, true));
     swap();
-    RC(t.mask(cur, t.a("d2a"), A_LRELU, L0 / 16, 128, 128, 128));
     RC(conv_bwd(8, "u2", 256, cur, 128, H2, W2, oth));
     swap();
-    RC(resize_bwd(H3, W3, 256));
+    RC(resize_bwd("e3b", H3, W3, 256));
     swap();
-    RC(t.mask(cur, t.a("e3b"), A_LRELU, L0 / 64, 256, 256, 256));
-    RC(conv_bwd(7, "e3a", 256, cur, 256, H3, W3, oth));
+    RC(conv_bwd(7, "e3a", 256, cur, 256, H3, W3, oth, true));
     swap();
-    RC(t.mask(cur, t.a("e3a"), A_LRELU, L0 / 64, 256, 256, 256));
     RC(conv_bwd(6, "p3", 128, cur, 256, H3, W3, oth));
     swap();
     RC(pool_bwd("e2b", H2, W2, 128));
     swap();
-    RC(t.mask(cur, t.a("e2b"), A_LRELU, L0 / 16, 128, 128, 128));
-    RC(conv_bwd(5, "e2a", 128, cur, 128, H2, W2, oth));
+    RC(conv_bwd(5, "e2a", 128, cur, 128, H2, W2, oth, true));
     swap();
-    RC(t.mask(cur, t.a("e2a"), A_LRELU, L0 / 16, 128, 128, 128));
     RC(conv_bwd(4, "p2", 64, cur, 128, H2, W2, oth));
     swap();
     RC(pool_bwd("e1b", H1, W1, 64));
     swap();
-    RC(t.mask(cur, t.a("e1b"), A_LRELU, L0 / 4, 64, 64, 64));
-    RC(conv_bwd(3, "e1a", 64, cur, 64, H1, W1, oth));
+    RC(conv_bwd(3, "e1a", 64, cur, 64, H1, W1, oth, true));
     swap();
-    RC(t.mask(cur, t.a("e1a"), A_LRELU, L0 / 4, 64, 64, 64));
     RC(conv_bwd(2, "p1", 32, cur, 64, H1, W1, oth));
     swap();
     RC(pool_bwd("e0b", H, W, 32));
     swap();
-    RC(t.mask(cur, t.a("e0b"), A_LRELU, L0, 32, 32, 32));
-    RC(conv_bwd(1, "e0a", 32, cur, 32, H, W, oth));
+    RC(conv_bwd(1, "e0a", 32, cur, 32, H, W, oth, true));
     swap();
-    RC(t.mask(cur, t.a("e0a"), A_LRELU, L0, 32, 32, 32));
     RC(conv_bwd(0, "x0", 16, cur, 32, H, W, nullptr));
     return SR_OK;
 }
@@ -679,7 +678,7 @@ int sr_op_maxpool2_bwd(int device, int B, int H, int W, int C, const float* x, c
     const size_t n = (size_t)B * H * W * C, no = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * C;
     float *d_x = d.put(x, n), *d_gy = d.put(gy, no), *d_gx = d.get(n);
     if (!d_x || !d_gy || !d_gx) return fail(nullptr, SR_ERR_HIP, "hipMalloc / copy failed");
-    LAUNCHCHK(nullptr, "maxpool2_bwd", launch_maxpool2_bwd(d_x, d_gy, d_gx, B, H, W, C, nullptr));
+    LAUNCHCHK(nullptr, "maxpool2_bwd", launch_maxpool2_bwd(d_x, d_gy, d_gx, B, H, W, C, A_NONE, nullptr));
     HIPCHK(nullptr, hipDeviceSynchronize());
     HIPCHK(nullptr, hipMemcpy(gx, d_gx, n * 4, hipMemcpyDeviceToHost));
     return SR_OK;
@@ -694,7 +693,7 @@ int sr_op_resize_bilinear_bwd(int device, int B, int H, int W, int C, int s, con
     const size_t n = (size_t)B * H * W * C;
     float *d_gy = d.put(gy, n * s * s), *d_gx = d.get(n);
     if (!d_gy || !d_gx) return fail(nullptr, SR_ERR_HIP, "hipMalloc / copy failed");
-    LAUNCHCHK(nullptr, "resize_bwd", launch_resize_bwd(d_gy, d_gx, B, H, W, C, s, C, 0, nullptr));
+    LAUNCHCHK(nullptr, "resize_bwd", launch_resize_bwd(d_gy, d_gx, B, H, W, C, s, C, 0, nullptr, A_NONE, nullptr));
     HIPCHK(nullptr, hipDeviceSynchronize());
     HIPCHK(nullptr, hipMemcpy(gx, d_gx, n * 4, hipMemcpyDeviceToHost));
     return SR_OK;

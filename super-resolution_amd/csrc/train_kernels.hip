@@ -692,8 +692,9 @@ hipError_t launch_act_bwd(float* g, const float* y, int act, long npix, int C, i
 
 // ================================================================== MaxPool2D 2x2 SAME backward
 // the gradient goes to the first maximum of the window in row-major order (TF MaxPoolGrad, torch)
+// act (A_RELU / A_LRELU, else none): x is that activation's output, its derivative is folded into the store
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx,
-                                    int B, int H, int W, int C) {
+                                    int B, int H, int W, int C, int act) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const long total = (long)B * Ho * Wo * C;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -704,7 +705,7 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __
     p /= Wo;
     const int oy = p % Ho;
     const int b = p / Ho;
-    const float g = gy[idx];
+    float g = gy[idx];
     int best = -1;
     float bv = 0.f;
     for (int k = 0; k < 4; ++k) {
@@ -716,6 +717,8 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __
             bv = v;
         }
     }
+    if (act == A_RELU) g = bv > 0.f ? g : 0.f;
+    else if (act == A_LRELU) g = bv > 0.f ? g : 0.2f * g;
     for (int k = 0; k < 4; ++k) {
         const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
         if (yy >= H || xx >= W) continue;
@@ -723,9 +726,10 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __
     }
 }
 
-hipError_t launch_maxpool2_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, hipStream_t s) {
+hipError_t launch_maxpool2_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int act,
+                               hipStream_t s) {
     const long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * C;
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, x, gy, gx, B, H, W, C);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, x, gy, gx, B, H, W, C, act);
     return hipGetLastError();
 }
 
@@ -742,8 +746,9 @@ __device__ __forceinline__ float resize_adj_weight(int Y, int y, int n, int s) {
     return w;
 }
 
+// ym (or nullptr): output [B,H,W,C] of the ReLU / LeakyReLU `act` that fed the resize; its derivative scales the store
 __global__ void resize_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int B, int H, int W, int C,
-                                  int s, int ocs, int accumulate) {
+                                  int s, int ocs, int accumulate, const float* __restrict__ ym, int act) {
     const long total = (long)B * H * W * C;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -764,14 +769,17 @@ __global__ void resize_bwd_kernel(const float* __restrict__ gy, float* __restric
             row += resize_adj_weight(X, x, W, s) * gy[(((size_t)b * Ho + Y) * Wo + X) * C + c];
         sum += wy * row;
     }
+    if (ym) sum = ym[idx] > 0.f ? sum : (act == A_LRELU ? 0.2f * sum : 0.f);
     float* o = gx + (((size_t)b * H + y) * W + x) * ocs + c;
     *o = accumulate ? *o + sum : sum;
 }
 
 hipError_t launch_resize_bwd(const float* gy, float* gx, int B, int H, int W, int C, int sc, int ocs, int accumulate,
-                             hipStream_t s) {
+                             const float* ym, int act, hipStream_t s) {
+    if (ym && act != A_RELU && act != A_LRELU) return hipErrorInvalidValue;
     const long total = (long)B * H * W * C;
-    hipLaunchKernelGGL(resize_bwd_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, gy, gx, B, H, W, C, sc, ocs, accumulate);
+    hipLaunchKernelGGL(resize_bwd_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, gy, gx, B, H, W, C, sc, ocs, accumulate,
+                       ym, act);
     return hipGetLastError();
 }
 
