@@ -118,7 +118,7 @@ int sr_srnet(sr_ctx* ctx, int B, const float* lr_t, const float* s_s, float* out
  * of a step is bracketed by HIP events on the ctx stream.  sr_profile_read
  * synchronises and returns, for layer i < *n, the accumulated milliseconds,
  * launch count, algorithmic FLOPs per launch and algorithmic HBM bytes per
- * launch, plus its name.  No reference counterpart (the reference times the whole
+ * launch (means over the launches that share the name), plus its name.  No reference counterpart (the reference times the whole
  * predict with datetime.now(), FRVSR.py:292-296). */
 int sr_profile_enable(sr_ctx* ctx, int enable);
 int sr_profile_count(const sr_ctx* ctx);

@@ -127,5 +127,17 @@ hipError_t launch_adam(float* p, float* m, float* v, const float* g, long n, flo
                        float gscale, hipStream_t s);
 // ents: srh::PackEnt {int32 src, uint32 dst}[n]
 hipError_t launch_repack(const float* kernel, const void* ents, int n, void* out, int prec, hipStream_t s);
+// batched form: job q re-packs params[src + ents[i].src] into out (ents == nullptr: copies n floats, a bias)
+struct RepackJob {
+    const void* ents;
+    void* out;
+    int n, src, block0, pad_;
+};
+struct RepackBatch {
+    static constexpr int MAXJ = 60;   // 60 x 32 B of kernel arguments
+    RepackJob j[MAXJ];
+    int njobs;
+};
+hipError_t launch_repack_batch(const float* params, RepackBatch& b, int prec, hipStream_t s);
 
 }  // namespace sr

@@ -870,8 +870,9 @@ int sr_profile_read(sr_ctx* c, int i, char* name_out, int name_cap, double* ms_t
     if (name_out && name_cap > 0) snprintf(name_out, name_cap, "%s", p.name.c_str());
     if (ms_total) *ms_total = p.ms;
     if (launches) *launches = p.launches;
-    if (flops_per_launch) *flops_per_launch = p.flops;
-    if (bytes_per_launch) *bytes_per_launch = p.bytes;
+    const double n = p.launches > 0 ? (double)p.launches : 1.0;
+    if (flops_per_launch) *flops_per_launch = p.flops / n;
+    if (bytes_per_launch) *bytes_per_launch = p.bytes / n;
     return SR_OK;
 }
 int sr_profile_reset(sr_ctx* c) {

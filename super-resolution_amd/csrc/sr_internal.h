@@ -131,8 +131,8 @@ struct ProfScope {
         if (!c || !c->prof_on) return;
         ProfEntry* p = prof_entry(c, name);
         idx = p - c->prof.data();
-        p->flops = flops;
-        p->bytes = bytes;
+        p->flops += flops;   // totals: launches sharing a name may differ in size; sr_profile_read reports the mean
+        p->bytes += bytes;
         p->launches++;
         e0 = get_event(c);
         e1 = get_event(c);

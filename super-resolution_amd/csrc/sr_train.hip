@@ -451,22 +451,35 @@ int grads_common(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const
 int repack_all(sr_ctx* c) {
     sr_train_state* T = c->train;
     hipStream_t st = c->stream;
+    RepackBatch rb;
+    rb.njobs = 0;
+    auto flush = [&]() -> int {
+        ProfScope ps(c, "train.repack", 0, 0);
+        LAUNCHCHK(c, "repack", launch_repack_batch(T->d_params, rb, c->prec, st));
+        rb.njobs = 0;
+        return SR_OK;
+    };
+    auto add = [&](const void* ents, int n, void* out, size_t src) -> int {
+        if (n <= 0 || !out) return SR_OK;
+        if (rb.njobs == RepackBatch::MAXJ) RC(flush());
+        rb.j[rb.njobs++] = {ents, out, n, (int)src, 0, 0};
+        return SR_OK;
+    };
     for (int g = 0; g < 2; ++g) {
         const bool is_f = g == 0;
         const int nl = is_f ? 14 : 24, base = is_f ? 0 : 28;
         for (int i = 0; i < nl; ++i) {
             ConvLayer& L = is_f ? c->fnet[i] : c->srnet[i];
-            const float* wk = T->d_params + T->off[base + 2 * i];
-            LAUNCHCHK(c, "repack", launch_repack(wk, L.d_ents, (int)L.ents.size(), L.d_w, c->prec, st));
-            HIPCHK(c, hipMemcpyAsync(L.d_bias, T->d_params + T->off[base + 2 * i + 1], (size_t)L.cout * 4, hipMemcpyDeviceToDevice, st));
+            const size_t wk = T->off[base + 2 * i];
+            RC(add(L.d_ents, (int)L.ents.size(), L.d_w, wk));
+            RC(add(nullptr, L.cout, L.d_bias, T->off[base + 2 * i + 1]));
             ConvLayer& D = is_f ? T->fnet_dg[i] : T->srnet_dg[i];
-            if (D.d_w) LAUNCHCHK(c, "repack", launch_repack(wk, D.d_ents, (int)D.ents.size(), D.d_w, c->prec, st));
+            if (D.d_w) RC(add(D.d_ents, (int)D.ents.size(), D.d_w, wk));
         }
     }
     ConvLayer& U = c->srnet[22];
-    if (U.d_proj)
-        LAUNCHCHK(c, "repack", launch_repack(T->d_params + T->off[28 + 46], U.d_proj_ents, (int)U.proj_ents.size(), U.d_proj, c->prec, st));
-    return SR_OK;
+    if (U.d_proj) RC(add(U.d_proj_ents, (int)U.proj_ents.size(), U.d_proj, T->off[28 + 46]));
+    return flush();
 }
 
 }  // namespace

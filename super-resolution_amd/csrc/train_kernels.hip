@@ -992,4 +992,45 @@ hipError_t launch_repack(const float* kernel, const void* ents, int n, void* out
     return hipGetLastError();
 }
 
+// Many re-packs in one launch (after Adam every conv's forward, data-gradient and projection buffer plus its
+// bias follow the master weights: ~110 jobs of a few thousand elements, which as separate launches cost more
+// in launch latency than in work).  The job table travels in the kernel arguments; a workgroup finds its job
+// by a uniform scan (scalar loads of the argument segment).
+__global__ void repack_batch_kernel(const float* __restrict__ params, const RepackBatch b, int prec) {
+    int k = 0;
+    for (int q = 1; q < b.njobs; ++q)
+        if (b.j[q].block0 <= (int)blockIdx.x) k = q;
+    const RepackJob J = b.j[k];
+    const int i = ((int)blockIdx.x - J.block0) * 256 + threadIdx.x;
+    if (i >= J.n) return;
+    if (!J.ents) {   // bias: plain copy
+        reinterpret_cast<float*>(J.out)[i] = params[J.src + i];
+        return;
+    }
+    const int2 e = reinterpret_cast<const int2*>(J.ents)[i];
+    const float v = params[J.src + e.x];
+    const unsigned dst = (unsigned)e.y;
+    if (prec == P_FP32) {
+        reinterpret_cast<float*>(J.out)[dst] = v;
+    } else {
+        unsigned short* o = reinterpret_cast<unsigned short*>(J.out);
+        const unsigned short hi = f2bf_dev(v);
+        o[dst] = hi;
+        if (prec == P_BF16X3) o[dst + 512] = f2bf_dev(v - __uint_as_float((unsigned)hi << 16));
+    }
+}
+
+hipError_t launch_repack_batch(const float* params, RepackBatch& b, int prec, hipStream_t s) {
+    if (b.njobs <= 0) return hipSuccess;
+    if (b.njobs > RepackBatch::MAXJ) return hipErrorInvalidValue;
+    int blocks = 0;
+    for (int q = 0; q < b.njobs; ++q) {
+        if (b.j[q].n <= 0 || !b.j[q].out) return hipErrorInvalidValue;
+        b.j[q].block0 = blocks;
+        blocks += (b.j[q].n + 255) / 256;
+    }
+    hipLaunchKernelGGL(repack_batch_kernel, dim3(blocks), dim3(256), 0, s, params, b, prec);
+    return hipGetLastError();
+}
+
 }  // namespace sr
