@@ -98,9 +98,12 @@ struct WgradArgs {
     int B, H, W;       // input spatial dims
     int cin, cout, xcs, ycs, convt;
     int x3;            // 1: operands split hi+lo bf16, three bf16 MFMAs per product (ctx dtype bf16x3); 0: fp32 MFMA
+    int defer_reduce = 0;   // 1: leave the slice partials in `part` (a workspace of this launch's own) for launch_wgrad_reduce_batch
 };
 size_t wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int convt);
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);
+// dw / db of every deferred launch in `list` from its partials, in one launch per 48 layers
+hipError_t launch_wgrad_reduce_batch(const WgradArgs* list, int n, hipStream_t s);
 // data gradient of Conv2DTranspose 3x3 s2: dy [B,2H,2W,ycs] (cout channels, a multiple of 64), w (3,3,cout,cin), dx [B,H,W,xcs];
 // relu_y (nullable, laid out like dx): the output of the ReLU that fed the layer, dx is zeroed where it is not positive
 hipError_t launch_dgrad_s2(const float* dy, const float* w, float* dx, const float* relu_y, int B, int H, int W, int cin,

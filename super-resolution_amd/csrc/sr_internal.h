@@ -53,6 +53,7 @@ struct ProfEntry {
 };
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline size_t round_up_sz(size_t v, size_t m = 256) { return (v + m - 1) / m * m; }
 
 }  // namespace srh
 

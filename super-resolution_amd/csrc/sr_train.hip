@@ -24,7 +24,8 @@ struct sr_train_state {
     bool host_stale = false;            // ctx->tensors older than d_params
     ConvLayer fnet_dg[14], srnet_dg[24];   // data-gradient convs of the Conv2D layers (planned where needed)
     std::map<std::string, float*> act;  // saved activations and gradient work buffers
-    float* part = nullptr;              // wgrad partial sums
+    float* part = nullptr;              // wgrad partial sums, one region per layer (reduced together at the end)
+    size_t part_bytes = 0;
     double* mse_part = nullptr;
     float* d_loss = nullptr;            // [sr, flow]
     // host batches: the two HR-sized inputs are copied on a second stream under FNet / the forward
@@ -110,7 +111,8 @@ int train_init(sr_ctx* c) {
                 H = 4 * h;
                 W = 4 * w;
             }
-            part_bytes = std::max(part_bytes, wgrad_workspace_bytes(B, H, W, cin, cout, mode == M_CONVT));
+            // every layer keeps its slice partials until the step's single batched reduction
+            part_bytes += round_up_sz(wgrad_workspace_bytes(B, H, W, cin, cout, mode == M_CONVT));
             if ((mode == M_CONVT && c->prec != P_BF16X3) || (is_f && i == 0) || cout <= 3) continue;   // <= 3 outputs: dgrad_few reads the master weights
             ConvLayer& D = is_f ? T->fnet_dg[i] : T->srnet_dg[i];
             plan_layer(D, c->prec, M_CONV, cout, cin);
@@ -122,6 +124,7 @@ int train_init(sr_ctx* c) {
         }
     }
     HIPCHK(c, hipMalloc((void**)&T->part, part_bytes));
+    T->part_bytes = part_bytes;
     // activation tape and gradient work buffers, fp32, per image sizes in floats
     const size_t L0 = (size_t)h * w, L1 = L0 / 4, L2 = L0 / 16, L3 = L0 / 64, Bz = B;
     struct { const char* n; size_t elems; } plan[] = {
@@ -158,6 +161,8 @@ struct Tape {
     sr_train_state* T;
     int B, P;
     hipStream_t st;
+    std::vector<WgradArgs> pending;   // weight gradients whose slice partials wait for reduce_all()
+    size_t part_off = 0;
     float* a(const char* n) { return T->act[n]; }
 
     int conv(const ConvLayer& L, const float* in, int H, int W, float* out, int out_cs, int cout_store, int act,
@@ -176,7 +181,6 @@ struct Tape {
         WgradArgs wa;
         wa.x = x;
         wa.dy = dy;
-        wa.part = T->part;
         wa.dw = T->d_grad + T->off[ti];
         wa.db = T->d_grad + T->off[ti + 1];
         wa.B = B;
@@ -188,11 +192,24 @@ struct Tape {
         wa.ycs = ycs;
         wa.convt = mode == M_CONVT;
         wa.x3 = P == P_BF16X3;
+        wa.defer_reduce = 1;
+        const size_t ws = round_up_sz(wgrad_workspace_bytes(B, H, W, cin, cout, wa.convt));
+        if (part_off + ws > T->part_bytes) return fail(c, SR_ERR_STATE, "wgrad workspace exhausted");
+        wa.part = T->part + part_off / 4;
+        part_off += ws;
+        pending.push_back(wa);
         const double px = (double)B * H * W;
         char nm[48];
         snprintf(nm, sizeof nm, "train.wgrad%s %d>%d @%dx%d", mode == M_CONVT ? "T" : "", cin, cout, H, W);
         ProfScope ps(c, nm, px * 18.0 * cin * cout, px * 4.0 * (cin + (mode == M_CONVT ? 4 : 1) * cout));
         LAUNCHCHK(c, "wgrad", launch_wgrad(wa, st));
+        return SR_OK;
+    }
+    int reduce_all() {
+        ProfScope ps(c, "train.wgrad_reduce", 0, (double)part_off);
+        LAUNCHCHK(c, "wgrad_reduce", launch_wgrad_reduce_batch(pending.data(), (int)pending.size(), st));
+        pending.clear();
+        part_off = 0;
         return SR_OK;
     }
     int mask(float* g, const float* y, int act, long npix, int C, int gcs, int ycs) {
@@ -400,7 +417,7 @@ int train_backward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const fl
     RC(conv_bwd(1, "e0a", 32, cur, 32, H, W, oth, true));
     swap();
     RC(conv_bwd(0, "x0", 16, cur, 32, H, W, nullptr));
-    return SR_OK;
+    return t.reduce_all();
 }
 
 int grads_common(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1, const float* hr_t,

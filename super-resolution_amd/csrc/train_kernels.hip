@@ -376,11 +376,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const WgradArgs a, con
 
 // dw / db = sum of the slices' partials in slice order (deterministic).  One workgroup: 32 consecutive
 // outputs x 8 slice lanes; lane g adds slices g, g + 8, ... and the eight sums meet in LDS in lane order.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                           float* __restrict__ db, const WgradPlan pl, int nbias) {
-    __shared__ float red[8][32];
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ dw,
+                                                  float* __restrict__ db, const WgradPlan& pl, int nbias, int block,
+                                                  float (&red)[8][32]) {
     const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int idx = blockIdx.x * 32 + e;
+    const int idx = block * 32 + e;
     const int nw = 9 * pl.R * pl.S;
     const size_t stride = (size_t)pl.nblk * pl.part;
     const int nacc = pl.part - 64;
@@ -393,7 +393,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         if (pl.mode == WG_TAPSN) off = (size_t)(r >> 5) * pl.part + (r & 31) * 32 + tap * pl.S + s;
         else off = (size_t)((r >> 5) * pl.ncolb + (s >> 5)) * pl.part + tap * 1024 + (r & 31) * 32 + (s & 31);
         const float* p = part + off;
-        for (int sl = g; sl < pl.nslices; sl += 8) sum += p[sl * stride];
+        // eight loads in flight per lane (the adds keep slice order): one at a time the kernel is latency-bound
+        int sl = g;
+        for (; sl + 56 < pl.nslices; sl += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(sl + 8 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
+        }
+        for (; sl < pl.nslices; sl += 8) sum += p[sl * stride];
     } else if (idx < nw + nbias) {
         const int c = idx - nw;
         size_t off;
@@ -414,6 +423,53 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           float* __restrict__ db, const WgradPlan pl, int nbias) {
+    __shared__ float red[8][32];
+    wgrad_reduce_body(part, dw, db, pl, nbias, blockIdx.x, red);
+}
+
+// the reductions of many layers in one launch (a training step defers all 38 of them to the end of the
+// backward pass: each alone is a 10 us launch with too few workgroups to fill the chip)
+struct WgradReduceJob {
+    const float* part;
+    float* dw;
+    float* db;
+    WgradPlan pl;
+    int nbias, block0;
+};
+struct WgradReduceBatch {
+    static constexpr int MAXJ = 48;   // 48 x 72 B of kernel arguments
+    WgradReduceJob j[MAXJ];
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradReduceBatch b) {
+    __shared__ float red[8][32];
+    int k = 0;
+    for (int q = 1; q < b.njobs; ++q)
+        if (b.j[q].block0 <= (int)blockIdx.x) k = q;
+    const WgradReduceJob J = b.j[k];
+    wgrad_reduce_body(J.part, J.dw, J.db, J.pl, J.nbias, (int)blockIdx.x - J.block0, red);
+}
+
+hipError_t launch_wgrad_reduce_batch(const WgradArgs* list, int n, hipStream_t s) {
+    for (int first = 0; first < n; first += WgradReduceBatch::MAXJ) {
+        WgradReduceBatch b;
+        b.njobs = std::min(n - first, (int)WgradReduceBatch::MAXJ);
+        int blocks = 0;
+        for (int q = 0; q < b.njobs; ++q) {
+            const WgradArgs& a = list[first + q];
+            b.j[q] = {a.part, a.dw, a.db, wgrad_plan(a.B, a.H, a.W, a.cin, a.cout, a.convt, a.x3), a.cout, blocks};
+            blocks += blocks_for(9 * a.cin * a.cout + a.cout, 32);
+        }
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks), dim3(256), 0, s, b);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
     const WgradPlan pl = wgrad_plan(a.B, a.H, a.W, a.cin, a.cout, a.convt, a.x3);
     const dim3 grid(wg_grid(pl)), block(256);
@@ -428,7 +484,7 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
     else
         hipLaunchKernelGGL(wgrad_kernel<WG_CONV>, grid, block, 0, s, a, pl);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || a.defer_reduce) return e;
     const int n = 9 * a.cin * a.cout + a.cout;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(n, 32)), dim3(256), 0, s, a.part, a.dw, a.db, pl, a.cout);
     return hipGetLastError();
