@@ -185,6 +185,19 @@ int sr_train_on_batch(sr_ctx* ctx, int B, const float* lr_t, const float* lr_tm1
                       const float* hr_t, float lr, float* losses);
 int64_t sr_train_iterations(const sr_ctx* ctx);   /* optimizer steps taken (Keras `iterations`) */
 
+/* One training iteration from HR clips, the loop body of reference FRVSR.py:103-156 (and TecoGAN.py:181-231)
+ * without its host round trips: hr = HOST array [n_clips, c_frames, 4h, 4w, 3], uint8 (hr_is_u8 = 1, the
+ * decoded frames; normalised on the device like utils.py:57-58) or float32 in [0,1].  On the device: LR =
+ * GaussianBlur 5x5 + cubic x1/4 (FRVSR.py:117-119), previous LR frame (zeros at frame 0), previous estimate =
+ * the generator's own no-gradient output for the previous frame, clips in lock step (zeros at frame 0), then
+ * forward + backward as sr_train_grads.  n_clips * c_frames <= max_batch.  sr_train_clips_grads leaves the
+ * flat gradient in the ctx (and in d_grads, a DEVICE pointer, when given) for sr_train_apply;
+ * sr_train_on_clips applies Keras-default Adam with learning rate lr itself.  losses as sr_train_on_batch. */
+int sr_train_clips_grads(sr_ctx* ctx, int n_clips, int c_frames, const void* hr, int hr_is_u8,
+                         float* d_grads, float* losses);
+int sr_train_on_clips(sr_ctx* ctx, int n_clips, int c_frames, const void* hr, int hr_is_u8, float lr,
+                      float* losses);
+
 /* Gradients of the single ops (host pointers, NHWC float32), for the parity tests against autograd
  * (dtype fp32 or bf16x3 selects the arithmetic of the convolution gradients):
  * Conv2D 3x3 'same' (x, w HWIO, dy) -> dx (nullable), dw (3,3,Cin,Cout), db (nullable);

@@ -150,19 +150,25 @@ class FrameRecurrentVideoSR(object):
             for j in picks:
                 if j not in clips:
                     clips[j] = load_clip(videos[j])
-                frames = get_frames(clips[j], self.configs, rng)
-                hr.append(normalize(frames) if frames.dtype == np.uint8 else frames.astype(np.float32))
-            net_input, net_output = self.make_train_batch(np.stack(hr))
+                hr.append(get_frames(clips[j], self.configs, rng))
+            # decoded uint8 frames go to the device as they are (normalised there); anything else as float32
+            if not all(f.dtype == np.uint8 for f in hr):
+                hr = [normalize(f) if f.dtype == np.uint8 else f.astype(np.float32) for f in hr]
+            hr = np.stack(hr)
             if lr_schedule is not None:
                 gen.optimizer.lr = float(lr_schedule(i))          # K.set_value(optimizer.lr, ...) in the reference
-            loss = gen.train_on_batch(net_input, net_output)
+            # LR synthesis, previous frames / estimates and train_on_batch in one device-resident call
+            # (make_train_batch + gen.train_on_batch is the same iteration through host arrays)
+            loss = gen.train_on_clips(hr)
             if rank == 0 and i % cfg['info_freq'] == 0:
                 print('[INFO]', '-' * 15, 'Iteration %d' % i, '-' * 15)
                 print('[INFO] Total loss: %f \t SR loss: %f \t Flow loss: %f \t Learning rate: %f'
                       % (loss[0], loss[1], loss[2], gen.optimizer.lr))
             if rank == 0 and i % cfg['sample_freq'] == 0:
-                est, _ = gen.predict([a[0:1] for a in net_input])
-                hr0, lr0 = net_output[0][0], net_input[0][0]
+                # first frame of the first clip, zero state (the reference's sample 0, FRVSR.py:165-170)
+                hr0 = normalize(hr[0, 0]) if hr.dtype == np.uint8 else hr[0, 0]
+                lr0 = sr_hip.blur_cubic_downscale(hr0[None], device=self.core.device)[0]
+                est, _ = gen.predict([lr0[None], np.zeros_like(lr0)[None], np.zeros_like(hr0)[None]])
                 bic = cubic_upscale4(lr0[None])[0]
                 print('[INFO] %s PSNR: %f \t Bicubic PSNR: %f' % (label, psnr(est[0], hr0), psnr(bic, hr0)))
                 window = np.concatenate([denormalize(np.clip(bic, 0, 1)), denormalize(np.clip(est[0], 0, 1)), denormalize(hr0)], axis=0)

@@ -448,6 +448,21 @@ __global__ void blur_cubic_down4_kernel(const float* __restrict__ hr, float* __r
     lr[idx] = acc;
 }
 
+__global__ void u8_normalize_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const uchar4 v = reinterpret_cast<const uchar4*>(in)[i];
+    // IEEE division like numpy's astype(float32) / 255.0 (hipcc keeps fp32 division correctly rounded)
+    reinterpret_cast<float4*>(out)[i] = make_float4(v.x / 255.0f, v.y / 255.0f, v.z / 255.0f, v.w / 255.0f);
+}
+
+hipError_t launch_u8_normalize(const unsigned char* in, float* out, size_t n, hipStream_t s) {
+    if (n % 4) return hipErrorInvalidValue;
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(u8_normalize_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, in, out, n4);
+    return hipGetLastError();
+}
+
 hipError_t launch_blur_cubic_down4(const float* hr, float* lr, int N, int H, int W, int C, hipStream_t s) {
     const long total = (long)N * (H / 4) * (W / 4) * C;
     hipLaunchKernelGGL(blur_cubic_down4_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, hr, lr, N, H, W, C);

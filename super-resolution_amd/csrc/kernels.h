@@ -79,6 +79,8 @@ hipError_t launch_warp3(const float* img, const float* flow, float* out, int B, 
 hipError_t launch_teco_epilogue(float* est, const float* lr_t, int B, int H, int W, hipStream_t s);
 
 // LR synthesis of the reference's drivers: GaussianBlur 5x5 (sigma 0 table, reflect-101) + cubic x1/4, hr [N,H,W,C] -> lr [N,H/4,W/4,C]
+// out[i] = in[i] / 255 (reference utils.py:57-58 normalize), n elements
+hipError_t launch_u8_normalize(const unsigned char* in, float* out, size_t n, hipStream_t s);
 hipError_t launch_blur_cubic_down4(const float* hr, float* lr, int N, int H, int W, int C, hipStream_t s);
 
 // generic fp32 single ops for the per-op C-ABI entry points

@@ -511,7 +511,10 @@ int run_step_lane(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, 
 int run_step(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, const float* d_est_prev,
              float* d_est_out, float* d_lr_warp, float* d_hr_warp, bool warp_only) {
     // profiling wants each kernel alone on the device; one image cannot be split
-    const int lanes = std::min(c->dual + 1, B);
+    // small steps (the 4 x 64 x 64 recurrence of a training iteration) are launch-bound: a second lane only
+    // doubles the launches (measured 14.6 -> 12.9 ms per iteration with one lane)
+    const bool tiny = (size_t)B * c->h * c->w <= 65536;
+    const int lanes = tiny ? 1 : std::min(c->dual + 1, B);
     if (lanes < 2 || c->prof_on)
         return run_step_lane(c, B, d_lr_t, d_lr_tm1, d_est_prev, d_est_out, d_lr_warp, d_hr_warp, warp_only);
     const size_t lr = (size_t)c->h * c->w * 3, hr = lr * 16;

@@ -162,6 +162,9 @@ struct ConvIO {
 
 int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, const ConvIO& io, const char* name);
 int check_ready(sr_ctx* c, int B);
+// one generator step on device pointers (sr_api.hip); d_est_out / d_lr_warp / d_hr_warp may be nullptr
+int run_step(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, const float* d_est_prev, float* d_est_out,
+             float* d_lr_warp, float* d_hr_warp, bool warp_only);
 
 // sr_train.hip
 void train_free(sr_ctx* c);

@@ -26,6 +26,10 @@ struct sr_train_state {
     std::map<std::string, float*> act;  // saved activations and gradient work buffers
     float* part = nullptr;              // wgrad partial sums, one region per layer (reduced together at the end)
     size_t part_bytes = 0;
+    // sr_train_clips_grads: frame-major staging, [n zero frames | frames] so that "previous frame" is a pointer offset
+    float* clip_lr = nullptr;           // (2 * max_batch) LR frames
+    float* clip_est = nullptr;          // max_batch HR frames: slot f + 1 = the generator's estimate of frame f
+    unsigned char* clip_u8 = nullptr;   // max_batch HR frames as uint8
     double* mse_part = nullptr;
     float* d_loss = nullptr;            // [sr, flow]
     // host batches: the two HR-sized inputs are copied on a second stream under FNet / the forward
@@ -448,7 +452,7 @@ int grads_common(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const
     HIPCHK(c, hipEventRecord(T->ev_est, cs));
     HIPCHK(c, hipStreamWaitEvent(st, T->ev_est, 0));
     if ((rc = train_forward(t, 2, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
-    HIPCHK(c, hipMemcpyAsync(T->act["hr"], hr_t, nhr, kind, cs));
+    if (hr_t != T->act["hr"]) HIPCHK(c, hipMemcpyAsync(T->act["hr"], hr_t, nhr, kind, cs));
     HIPCHK(c, hipEventRecord(T->ev_hr, cs));
     HIPCHK(c, hipStreamWaitEvent(st, T->ev_hr, 0));
     if ((rc = train_backward(t, c->d_lr_t, c->d_lr_tm1, c->d_est[0], T->act["hr"], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
@@ -510,6 +514,8 @@ void train_free(sr_ctx* c) {
     for (auto p : fl)
         if (p) (void)hipFree(p);
     if (T->mse_part) (void)hipFree(T->mse_part);
+    for (void* p : {(void*)T->clip_lr, (void*)T->clip_est, (void*)T->clip_u8})
+        if (p) (void)hipFree(p);
     if (T->copy_stream) {
         (void)hipStreamSynchronize(T->copy_stream);
         (void)hipStreamDestroy(T->copy_stream);
@@ -591,6 +597,60 @@ int sr_train_apply(sr_ctx* c, const float* d_grads, float grad_scale, float lr, 
 int sr_train_on_batch(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1, const float* hr_t,
                       float lr, float* losses) {
     int rc = grads_common(c, B, lr_t, lr_tm1, est_tm1, hr_t, nullptr, losses, false);
+    if (rc) return rc;
+    return sr_train_apply(c, nullptr, 1.f, lr, 0.9f, 0.999f, 1e-7f);
+}
+
+// Training iteration from HR clips (reference FRVSR.py:103-156 without its per-sample host round trips):
+// the HR frames go to the device once (uint8 or float), LR synthesis, the no-gradient recurrence that makes
+// the previous estimates, and forward + backward all run on device-resident tensors.  Internally the batch is
+// frame-major (sample = frame * n_clips + clip): a step of the recurrence is then one contiguous batch and
+// "previous LR frame / previous estimate" are the same buffers n_clips frames earlier, behind n_clips zero
+// frames.  The loss and the gradient are sums over the samples, so the order does not change them.
+int sr_train_clips_grads(sr_ctx* c, int n_clips, int c_frames, const void* hr, int hr_is_u8, float* d_grads, float* losses) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    if (!hr) return fail(c, SR_ERR_ARG, "NULL tensor pointer");
+    if (n_clips < 1 || c_frames < 1) return fail(c, SR_ERR_ARG, "n_clips and c_frames must be positive");
+    const int B = n_clips * c_frames;
+    int rc = check_ready(c, B);
+    if (rc) return rc;
+    if ((rc = train_init(c))) {
+        train_free(c);
+        return rc;
+    }
+    sr_train_state* T = c->train;
+    const size_t fl = (size_t)c->h * c->w * 3, fh = fl * 16;   // floats per LR / HR frame
+    if (!T->clip_lr) {
+        HIPCHK(c, hipMalloc((void**)&T->clip_lr, 2 * (size_t)c->max_batch * fl * 4));
+        HIPCHK(c, hipMalloc((void**)&T->clip_est, (size_t)c->max_batch * fh * 4));
+        HIPCHK(c, hipMalloc((void**)&T->clip_u8, (size_t)c->max_batch * fh));
+    }
+    c->clip_active = false;   // the recurrence borrows the ctx's work buffers
+    hipStream_t st = c->stream;
+    float* d_hr = T->act["hr"];
+    float* d_lr = T->clip_lr + (size_t)n_clips * fl;
+    // clip-major host frames -> frame-major device frames: one strided copy per clip
+    const size_t esz = hr_is_u8 ? 1 : 4;
+    unsigned char* dst0 = hr_is_u8 ? T->clip_u8 : (unsigned char*)d_hr;
+    for (int k = 0; k < n_clips; ++k)
+        HIPCHK(c, hipMemcpy2DAsync(dst0 + (size_t)k * fh * esz, (size_t)n_clips * fh * esz,
+                                   (const unsigned char*)hr + (size_t)k * c_frames * fh * esz, fh * esz, fh * esz, c_frames,
+                                   hipMemcpyHostToDevice, st));
+    if (hr_is_u8) LAUNCHCHK(c, "u8_normalize", launch_u8_normalize(T->clip_u8, d_hr, (size_t)B * fh, st));
+    HIPCHK(c, hipMemsetAsync(T->clip_lr, 0, (size_t)n_clips * fl * 4, st));
+    HIPCHK(c, hipMemsetAsync(T->clip_est, 0, (size_t)n_clips * fh * 4, st));
+    LAUNCHCHK(c, "blur_cubic_down4", launch_blur_cubic_down4(d_hr, d_lr, B, 4 * c->h, 4 * c->w, 3, st));
+    for (int f = 0; f + 1 < c_frames; ++f) {
+        const size_t o = (size_t)f * n_clips;
+        if ((rc = run_step(c, n_clips, d_lr + o * fl, T->clip_lr + o * fl, T->clip_est + o * fh, T->clip_est + (o + n_clips) * fh,
+                           nullptr, nullptr, false)))
+            return rc;
+    }
+    return grads_common(c, B, d_lr, T->clip_lr, T->clip_est, d_hr, d_grads, losses, true);
+}
+
+int sr_train_on_clips(sr_ctx* c, int n_clips, int c_frames, const void* hr, int hr_is_u8, float lr, float* losses) {
+    int rc = sr_train_clips_grads(c, n_clips, c_frames, hr, hr_is_u8, nullptr, losses);
     if (rc) return rc;
     return sr_train_apply(c, nullptr, 1.f, lr, 0.9f, 0.999f, 1e-7f);
 }

@@ -355,6 +355,30 @@ class GeneratorModel(_CoreModel):
         self.core._dirty = True
         return losses
 
+    def train_on_clips(self, hr_clips):
+        """One iteration of the reference's training loop body (FRVSR.py:103-156) from the HR clips alone:
+        hr_clips [n_clips, c_frames, H, W, 3], uint8 frames or float32 in [0,1].  LR synthesis, previous
+        frames / estimates (lock-step no-gradient recurrence) and the train_on_batch step all happen on the
+        device (sr_train_clips_grads); returns [total, sr_loss, flow_loss].  Same data-parallel rule as
+        train_on_batch."""
+        if self.optimizer is None:
+            raise RuntimeError('You must compile a model before training/testing. Use `model.compile(optimizer, loss)`.')
+        hr_clips = np.asarray(hr_clips)
+        ctx = self.core.ctx(hr_clips.shape[0] * hr_clips.shape[1])
+        opt = self.optimizer
+        import dp
+        if dp.world()[1] > 1:
+            dp.init_if_needed()
+            if getattr(self, '_gbuf', None) is None:
+                self._gbuf = dp.GradBuffer(ctx.param_count(), self.core.device)
+            losses = self._gbuf.reduce(ctx.train_clips_grads(hr_clips, d_grads=self._gbuf.ptr()))
+            ctx.train_apply(d_grads=self._gbuf.ptr(), lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon)
+        else:
+            losses = ctx.train_clips_grads(hr_clips)
+            ctx.train_apply(lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon)
+        self.core._dirty = True
+        return losses
+
     # device-resident recurrence (state never leaves the GPU); used by the eval drivers
     def clip_begin(self, batch):
         self._clip_ctx = self.core.ctx(batch)

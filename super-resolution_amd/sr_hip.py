@@ -60,6 +60,8 @@ SIGNATURES = {
     "sr_train_apply": (C.c_int, [_vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     "sr_train_on_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_float, _f32p]),
     "sr_train_iterations": (C.c_int64, [_vp]),
+    "sr_train_clips_grads": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _f32p]),
+    "sr_train_on_clips": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_float, _f32p]),
     "sr_op_conv3x3_bwd": (C.c_int, [C.c_int] * 7 + [_vp] * 6),
     "sr_op_convT3x3s2_bwd": (C.c_int, [C.c_int] * 7 + [_vp] * 6),
     "sr_op_maxpool2_bwd": (C.c_int, [C.c_int] * 5 + [_vp] * 3),
@@ -269,6 +271,34 @@ class Context:
 
     def train_iterations(self):
         return int(lib().sr_train_iterations(self._h))
+
+    def _clips_in(self, hr_clips):
+        """[n_clips, c_frames, 4h, 4w, 3] uint8 (decoded frames) or float32 in [0,1] -> (array, n, c, is_u8)."""
+        a = np.asarray(hr_clips)
+        want = (4 * self.h, 4 * self.w, 3)
+        if a.ndim != 5 or tuple(a.shape[2:]) != want:
+            raise ValueError(f"HR clips: expected shape (n_clips, c_frames) + {want}, got {tuple(a.shape)}")
+        if a.dtype != np.uint8:
+            a = a.astype(np.float32, copy=False)
+        a = np.ascontiguousarray(a)
+        if a.shape[0] * a.shape[1] > self.max_batch:
+            raise ValueError(f"n_clips * c_frames = {a.shape[0] * a.shape[1]} exceeds the ctx's max_batch {self.max_batch}")
+        return a, int(a.shape[0]), int(a.shape[1]), int(a.dtype == np.uint8)
+
+    def train_clips_grads(self, hr_clips, d_grads=None):
+        """Forward + backward of one training iteration built on the device from HR clips (LR synthesis,
+        no-gradient recurrence for the previous estimates; reference FRVSR.py:103-156)."""
+        a, n, c, u8 = self._clips_in(hr_clips)
+        losses = (C.c_float * 3)()
+        _check(lib().sr_train_clips_grads(self._h, n, c, a.ctypes.data_as(C.c_void_p), u8,
+                                          _vp(d_grads) if d_grads else None, losses), self._h)
+        return list(losses)
+
+    def train_on_clips(self, hr_clips, lr=1e-4):
+        a, n, c, u8 = self._clips_in(hr_clips)
+        losses = (C.c_float * 3)()
+        _check(lib().sr_train_on_clips(self._h, n, c, a.ctypes.data_as(C.c_void_p), u8, lr, losses), self._h)
+        return list(losses)
 
     def split_grads(self, flat):
         """flat gradient / parameter vector -> {keras name: array} in file order."""

@@ -315,3 +315,52 @@ def test_device_pointer_entry_points(sh, weights7):
         np.testing.assert_array_equal(a, b)
     ctx.close()
     ctx2.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_train_on_clips_equals_the_host_built_batch(sh, weights7, dtype):
+    """sr_train_clips_grads (HR clips in, everything else on the device, frame-major inside) against the same
+    iteration assembled on the host from the public pieces in the reference's sample order b = clip*c + frame
+    (FRVSR.py:115-155): blur_cubic_downscale, lock-step recurrence through step(), train_grads."""
+    n, c, h, w = 3, 4, 16, 16
+    rng = np.random.RandomState(77)
+    hr_u8 = rng.randint(0, 256, size=(n, c, 4 * h, 4 * w, 3)).astype(np.uint8)
+    # smooth the frames a little so that consecutive ones are related (random noise warps to noise anyway)
+    hr = (hr_u8.astype(np.float32) / 255.0)
+    ctx = sh.Context(h, w, max_batch=n * c, dtype=dtype)
+    ctx.load_weights(weights7)
+    lr = sh.blur_cubic_downscale(hr.reshape((n * c, 4 * h, 4 * w, 3))).reshape((n, c, h, w, 3))
+    prev_lr = np.zeros_like(lr)
+    prev_lr[:, 1:] = lr[:, :-1]
+    prev_est = np.zeros_like(hr)
+    for f in range(c - 1):
+        prev_est[:, f + 1] = ctx.step(lr[:, f], prev_lr[:, f], prev_est[:, f], want_lr_warp=False)[0]
+    flat = lambda a: np.ascontiguousarray(a.reshape((n * c,) + a.shape[2:]))
+    want_l, want_g = ctx.train_grads(flat(lr), flat(prev_lr), flat(prev_est), flat(hr), read=True)
+    for clips in (hr, hr_u8):                                  # float32 and uint8 frames: the same numbers
+        got_l = ctx.train_clips_grads(clips)
+        got_g = np.empty(ctx.param_count(), np.float32)
+        assert sh.lib().sr_train_read_grads(ctx._h, got_g.ctypes.data_as(C.c_void_p)) == 0
+        assert np.allclose(got_l, want_l, rtol=1e-5), (got_l, want_l)
+        # same per-sample arithmetic, only the order of the sums over samples differs
+        assert rel_err(got_g, want_g) <= 2e-5, rel_err(got_g, want_g)
+    # the Adam variant moves the weights like train_on_batch on the host-built batch
+    ctx2 = sh.Context(h, w, max_batch=n * c, dtype=dtype)
+    ctx2.load_weights(weights7)
+    ctx2.train_on_batch(flat(lr), flat(prev_lr), flat(prev_est), flat(hr), lr=1e-4)
+    ctx3 = sh.Context(h, w, max_batch=n * c, dtype=dtype)
+    ctx3.load_weights(weights7)
+    ctx3.train_on_clips(hr_u8, lr=1e-4)
+    assert ctx3.train_iterations() == 1
+    gsplit = ctx.split_grads(want_g)
+    for (name, a), (_, b), (_, a0) in zip(ctx2.get_weights(), ctx3.get_weights(), ctx.get_weights()):
+        # first Adam step = lr * g / (|g| + eps) ~ lr * sign(g): compare the steps where the gradient is not noise
+        g = gsplit[name]
+        m = np.abs(g) > 1e-2 * np.max(np.abs(g))
+        assert np.allclose((a - a0)[m], (b - a0)[m], atol=2e-6), name
+    with pytest.raises(ValueError):
+        ctx.train_clips_grads(np.zeros((n + 1, c, 4 * h, 4 * w, 3), np.uint8))   # exceeds max_batch
+    with pytest.raises(ValueError):
+        ctx.train_clips_grads(np.zeros((n, c, 4 * h, 4 * w + 4, 3), np.uint8))
+    for x in (ctx, ctx2, ctx3):
+        x.close()

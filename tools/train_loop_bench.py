@@ -1,6 +1,8 @@
 """Times whole iterations of stage.train through the facade (reference FRVSR.py:100-200, config 4: batch_size 4 clips
 x c_frames 10 frames of 256x256 HR / 64x64 LR): clip sampling, LR synthesis, the no-gradient recurrence that
-makes the previous estimates, train_on_batch.  Synthetic .npy clips in a temporary directory.
+makes the previous estimates, train_on_batch -- first through host arrays (make_train_batch + train_on_batch,
+the reference's own call sequence), then as the loop runs it: uint8 clips in, one device-resident call
+(GeneratorModel.train_on_clips = sr_train_clips_grads + sr_train_apply).  Synthetic .npy clips in a temporary directory.
 
     python tools/train_loop_bench.py [--iters 20] [--dtype bf16x3]
 """
@@ -57,6 +59,21 @@ def main():
     print(f"stage.train iteration (4 clips x 10 frames, {a.dtype}): {dt * 1e3:.1f} ms = {40 / dt:.0f} samples/s; "
           f"clip sampling + normalize {t['sample'] / a.iters * 1e3:.1f} ms, LR synthesis + recurrence {t['batch'] / a.iters * 1e3:.1f} ms, "
           f"train_on_batch {t['step'] / a.iters * 1e3:.1f} ms; loss {loss[0]:.4f}")
+    t = {"sample": 0.0, "step": 0.0}
+    for it in range(a.iters + 2):
+        if it == 2:
+            t = dict.fromkeys(t, 0.0)
+            t0 = time.perf_counter()
+        s0 = time.perf_counter()
+        hr = np.stack([utils.get_frames(clips[j], cfg, r) for j in r.randint(0, len(clips), size=4)])   # uint8
+        s1 = time.perf_counter()
+        loss = m.frvsr.train_on_clips(hr)
+        s2 = time.perf_counter()
+        t["sample"] += s1 - s0
+        t["step"] += s2 - s1
+    dt = (time.perf_counter() - t0) / a.iters
+    print(f"stage.train iteration, device-resident (train_on_clips, uint8 frames in): {dt * 1e3:.1f} ms = {40 / dt:.0f} samples/s; "
+          f"clip sampling {t['sample'] / a.iters * 1e3:.1f} ms, train_on_clips {t['step'] / a.iters * 1e3:.1f} ms; loss {loss[0]:.4f}")
 
 
 if __name__ == "__main__":
