@@ -424,8 +424,10 @@ int train_backward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const fl
     return t.reduce_all();
 }
 
+// n_clips > 0 (sr_train_clips_grads): est_tm1 is the frame-major estimate buffer whose slots 1.. are still to be
+// made -- after FNet has run on the whole batch, by the frame-by-frame recurrence on the flows it just produced
 int grads_common(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1, const float* hr_t,
-                 float* d_grads_out, float* losses, bool dev) {
+                 float* d_grads_out, float* losses, bool dev, int n_clips = 0) {
     int rc = check_ready(c, B);
     if (rc) return rc;
     if (!lr_t || !lr_tm1 || !est_tm1 || !hr_t) return fail(c, SR_ERR_ARG, "NULL tensor pointer");
@@ -448,9 +450,22 @@ int grads_common(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const
     HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, lr_tm1, nlr, kind, st));
     Tape t{c, T, B, c->prec, st};
     if ((rc = train_forward(t, 1, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, kind, cs));
-    HIPCHK(c, hipEventRecord(T->ev_est, cs));
-    HIPCHK(c, hipStreamWaitEvent(st, T->ev_est, 0));
+    if (n_clips > 0) {
+        // no-gradient recurrence (reference FRVSR.py:124-151): frame f's estimate from its flow, its LR frame and
+        // the estimate of frame f - 1, for all clips at once; FNet of (lr_f, lr_f-1) is the pass that just ran
+        float* est = const_cast<float*>(est_tm1);
+        const size_t fl = (size_t)c->h * c->w, fh = fl * 48;
+        for (int f = 0; f + 1 < B / n_clips; ++f) {
+            const size_t o = (size_t)f * n_clips;
+            if ((rc = run_step_given_flow(c, n_clips, c->d_flow + o * fl * 2, c->d_lr_t + o * fl * 3, est + o * fh, est + (o + n_clips) * fh)))
+                return rc;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, kind, st));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, kind, cs));
+        HIPCHK(c, hipEventRecord(T->ev_est, cs));
+        HIPCHK(c, hipStreamWaitEvent(st, T->ev_est, 0));
+    }
     if ((rc = train_forward(t, 2, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
     if (hr_t != T->act["hr"]) HIPCHK(c, hipMemcpyAsync(T->act["hr"], hr_t, nhr, kind, cs));
     HIPCHK(c, hipEventRecord(T->ev_hr, cs));
@@ -640,13 +655,7 @@ int sr_train_clips_grads(sr_ctx* c, int n_clips, int c_frames, const void* hr, i
     HIPCHK(c, hipMemsetAsync(T->clip_lr, 0, (size_t)n_clips * fl * 4, st));
     HIPCHK(c, hipMemsetAsync(T->clip_est, 0, (size_t)n_clips * fh * 4, st));
     LAUNCHCHK(c, "blur_cubic_down4", launch_blur_cubic_down4(d_hr, d_lr, B, 4 * c->h, 4 * c->w, 3, st));
-    for (int f = 0; f + 1 < c_frames; ++f) {
-        const size_t o = (size_t)f * n_clips;
-        if ((rc = run_step(c, n_clips, d_lr + o * fl, T->clip_lr + o * fl, T->clip_est + o * fh, T->clip_est + (o + n_clips) * fh,
-                           nullptr, nullptr, false)))
-            return rc;
-    }
-    return grads_common(c, B, d_lr, T->clip_lr, T->clip_est, d_hr, d_grads, losses, true);
+    return grads_common(c, B, d_lr, T->clip_lr, T->clip_est, d_hr, d_grads, losses, true, n_clips);
 }
 
 int sr_train_on_clips(sr_ctx* c, int n_clips, int c_frames, const void* hr, int hr_is_u8, float lr, float* losses) {
