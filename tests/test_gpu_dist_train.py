@@ -1,7 +1,8 @@
 """Data-parallel training end to end on the GPU box: two processes (both on cuda:0, gloo for the exchange because
 RCCL wants one GPU per rank) run GeneratorModel.train_on_batch on their halves of a batch -- sr_train_grads into
 the torch gradient buffer, mean over the ranks, sr_train_apply -- and must end with the weights a single
-process gets from the whole batch.  On a multi-GPU node the same code runs with backend nccl (= RCCL)."""
+process gets from the whole batch; then one device-resident iteration (train_on_clips) on one clip per rank against
+a single process on both clips.  On a multi-GPU node the same code runs with backend nccl (= RCCL)."""
 import os
 import socket
 import sys
@@ -28,6 +29,10 @@ def _batch(B, h, w):
             rng.random((B, 4 * h, 4 * w, 3), dtype=np.float32), rng.random((B, 4 * h, 4 * w, 3), dtype=np.float32)]
 
 
+def _clips(n):
+    return np.random.default_rng(5).integers(0, 256, (n, 2, 64, 64, 3), dtype=np.uint8)   # 2 frames: fits the max_batch of the steps before
+
+
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", SR_DIST_BACKEND="gloo")
@@ -48,7 +53,9 @@ def _worker(rank, world, port, out):
     losses = []
     for _ in range(2):
         losses.append(m.train_on_batch([a[sl], b[sl], c[sl]], [hr[sl], a[sl]]))
-    out.put((rank, losses, [x.copy() for x in m.get_weights()]))
+    w_batch = [x.copy() for x in m.get_weights()]
+    l_clips = m.train_on_clips(_clips(world)[rank:rank + 1])
+    out.put((rank, losses, w_batch, l_clips, [x.copy() for x in m.get_weights()]))
     import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()
@@ -75,12 +82,20 @@ def test_two_ranks_train_like_one_process_on_the_whole_batch(weights7):
     m.compile(loss=["mean_squared_error"] * 2, loss_weights=[1., 1.], optimizer=Adam(lr=1e-4))
     a, b, c, hr = _batch(2 * world, 16, 16)
     want_l = [m.train_on_batch([a, b, c], [hr, a]) for _ in range(2)]
-    want_w = m.get_weights()
-    for rank, losses, weights in got:
+    want_w = [x.copy() for x in m.get_weights()]
+    want_lc = m.train_on_clips(_clips(world))
+    want_wc = m.get_weights()
+    for rank, losses, weights, l_clips, weights_c in got:
         assert np.allclose(losses, want_l, rtol=1e-5), (rank, losses, want_l)          # mean of the shard losses = batch loss
         d = np.concatenate([np.abs(x - y).ravel() for x, y in zip(weights, want_w)])
         # same gradient up to summation order -> same Adam steps (2 x 1e-4); elements with a gradient at rounding
         # level may differ by a fraction of a step
         assert d.mean() <= 0.01 * 2e-4 and np.quantile(d, 0.999) <= 0.5 * 2e-4, (rank, d.mean(), d.max())
-    for x, y in zip(got[0][2], got[1][2]):
-        np.testing.assert_array_equal(x, y)                                            # the ranks stay in lock step exactly
+        # the device-resident iteration shards by clip: one clip per rank == both clips in one process
+        # (the weights the ranks start it from differ from the single process's by the rounding-level steps above)
+        assert np.allclose(l_clips, want_lc, rtol=1e-3), (rank, l_clips, want_lc)
+        d = np.concatenate([np.abs(x - y).ravel() for x, y in zip(weights_c, want_wc)])
+        assert d.mean() <= 0.01 * 3e-4 and np.quantile(d, 0.999) <= 0.5 * 3e-4, (rank, d.mean(), d.max())
+    for k in (2, 4):
+        for x, y in zip(got[0][k], got[1][k]):
+            np.testing.assert_array_equal(x, y)                                        # the ranks stay in lock step exactly
