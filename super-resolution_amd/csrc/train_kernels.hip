@@ -9,17 +9,21 @@
 //                 split hi + lo once per row window; wgrad_kernel (ctx fp32): v_mfma_f32_32x32x2_f32; mode 2
 //                 folds the taps of a <= 3-output conv into N.  Slices of the pixel range go to different
 //                 waves, the four waves of a workgroup add up through LDS, a second kernel sums the
-//                 partials in a fixed order (deterministic).
+//                 partials in a fixed order (deterministic): per launch (wgrad_reduce_kernel) or, for a
+//                 training step, all layers in one launch at the end (wgrad_reduce_batch_kernel).
 //   dgrad_s2      data gradient of Conv2DTranspose s2 = 3x3 stride-2 convolution of dY with the same
 //                 kernel; pixels are the M dimension, each lane streams contiguous channels of its pixel
 //                 per tap; bf16x3 variant on forward-packed hi / lo weight fragments, fp32 variant on the
 //                 Keras-layout tensor through L1; the producer's ReLU mask is folded into the store.
 //   dgrad_few     data gradient of the convs with <= 3 outputs (HBM bound), activation mask in the store
 //   (the data gradient of the other stride-1 convolutions runs on the forward MFMA kernel of conv_mfma.hip
-//    with mirrored, transposed weights: sr_api.hip pack_entries PK_DGRAD)
-//   act_bwd, maxpool2_bwd, resize_bwd, warp_bwd_flow, hr_warp_bwd, mse_grad: HBM-bound gathers
+//    with mirrored, transposed weights: sr_api.hip pack_entries PK_DGRAD; its MASK epilogue applies the
+//    derivative of the activation whose output the gradient lands on)
+//   act_bwd, maxpool2_bwd, resize_bwd, warp_bwd_flow, hr_warp_bwd, mse_grad: HBM-bound gathers; the pool and
+//                 resize adjoints fold the LeakyReLU derivative of the tensor they write
 //   adam, repack  optimizer update on the flat parameter vector and the re-pack of the updated
-//                 kernels into the MFMA fragment order of the forward / dgrad convolutions.
+//                 kernels into the MFMA fragment order of the forward / dgrad convolutions (repack_batch:
+//                 every buffer of the network in two launches, job table in the kernel arguments).
 #include "kernels.h"
 #include "gather_math.h"
 
