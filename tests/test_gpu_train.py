@@ -364,3 +364,21 @@ def test_train_on_clips_equals_the_host_built_batch(sh, weights7, dtype):
         ctx.train_clips_grads(np.zeros((n, c, 4 * h, 4 * w + 4, 3), np.uint8))
     for x in (ctx, ctx2, ctx3):
         x.close()
+
+
+def test_train_on_clips_single_frame_is_the_zero_state_step(sh, weights7):
+    """c_frames = 1: no recurrence at all, every sample is a first frame (zero previous LR frame and estimate,
+    reference FRVSR.py:124-125); ragged frame size (24 x 40 LR) on the way."""
+    n, h, w = 2, 24, 40
+    hr_u8 = np.random.RandomState(5).randint(0, 256, size=(n, 1, 4 * h, 4 * w, 3)).astype(np.uint8)
+    hr = hr_u8[:, 0].astype(np.float32) / 255.0
+    ctx = sh.Context(h, w, max_batch=n, dtype="fp32")
+    ctx.load_weights(weights7)
+    lr = sh.blur_cubic_downscale(hr)
+    want_l, want_g = ctx.train_grads(lr, np.zeros_like(lr), np.zeros_like(hr), hr, read=True)
+    got_l = ctx.train_clips_grads(hr_u8)
+    got_g = np.empty(ctx.param_count(), np.float32)
+    assert sh.lib().sr_train_read_grads(ctx._h, got_g.ctypes.data_as(C.c_void_p)) == 0
+    assert np.allclose(got_l, want_l, rtol=1e-6)
+    assert np.array_equal(got_g, want_g)            # same samples in the same order: bit identical
+    ctx.close()
