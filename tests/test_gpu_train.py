@@ -317,8 +317,8 @@ def test_device_pointer_entry_points(sh, weights7):
     ctx2.close()
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
-def test_train_on_clips_equals_the_host_built_batch(sh, weights7, dtype):
+@pytest.mark.parametrize("dtype,model", [("fp32", "frvsr"), ("bf16x3", "frvsr"), ("fp32", "tecogan")])
+def test_train_on_clips_equals_the_host_built_batch(sh, weights7, dtype, model):
     """sr_train_clips_grads (HR clips in, everything else on the device, frame-major inside) against the same
     iteration assembled on the host from the public pieces in the reference's sample order b = clip*c + frame
     (FRVSR.py:115-155): blur_cubic_downscale, lock-step recurrence through step(), train_grads."""
@@ -327,7 +327,7 @@ def test_train_on_clips_equals_the_host_built_batch(sh, weights7, dtype):
     hr_u8 = rng.randint(0, 256, size=(n, c, 4 * h, 4 * w, 3)).astype(np.uint8)
     # smooth the frames a little so that consecutive ones are related (random noise warps to noise anyway)
     hr = (hr_u8.astype(np.float32) / 255.0)
-    ctx = sh.Context(h, w, max_batch=n * c, dtype=dtype)
+    ctx = sh.Context(h, w, max_batch=n * c, dtype=dtype, model=model)
     ctx.load_weights(weights7)
     lr = sh.blur_cubic_downscale(hr.reshape((n * c, 4 * h, 4 * w, 3))).reshape((n, c, h, w, 3))
     prev_lr = np.zeros_like(lr)
@@ -345,10 +345,10 @@ def test_train_on_clips_equals_the_host_built_batch(sh, weights7, dtype):
         # same per-sample arithmetic, only the order of the sums over samples differs
         assert rel_err(got_g, want_g) <= 2e-5, rel_err(got_g, want_g)
     # the Adam variant moves the weights like train_on_batch on the host-built batch
-    ctx2 = sh.Context(h, w, max_batch=n * c, dtype=dtype)
+    ctx2 = sh.Context(h, w, max_batch=n * c, dtype=dtype, model=model)
     ctx2.load_weights(weights7)
     ctx2.train_on_batch(flat(lr), flat(prev_lr), flat(prev_est), flat(hr), lr=1e-4)
-    ctx3 = sh.Context(h, w, max_batch=n * c, dtype=dtype)
+    ctx3 = sh.Context(h, w, max_batch=n * c, dtype=dtype, model=model)
     ctx3.load_weights(weights7)
     ctx3.train_on_clips(hr_u8, lr=1e-4)
     assert ctx3.train_iterations() == 1
