@@ -508,26 +508,6 @@ int run_step_lane(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, 
     return SR_OK;
 }
 
-// the step behind FNet: flow already known (the training iteration computes the flows of all frames in one
-// batched FNet pass and feeds them to the frame-by-frame recurrence); one lane on the ctx stream
-int run_step_given_flow(sr_ctx* c, int B, const float* d_flow, const float* d_lr_t, const float* d_est_prev, float* d_est_out) {
-    const int bf = c->prec == P_BF16;
-    const int H = c->h, W = c->w;
-    hipStream_t st = lane_st(c);
-    {
-        const double bytes = (double)B * H * W * (4.0 * (2 + 48 + 3) + 64.0 * (bf ? 2 : 4));
-        ProfScope ps(c, "pre_srnet", 0, bytes);
-        LAUNCHCHK(c, "pre_srnet", launch_pre_srnet(d_flow, d_est_prev, d_lr_t, lane_buf(c, "s_in"), nullptr, bf, B, H, W, st));
-    }
-    int rc = run_srnet(c, B, d_est_out);
-    if (rc) return rc;
-    if (c->model == SR_TECOGAN) {
-        ProfScope ps(c, "teco_epilogue", 0, (double)B * H * W * (12.0 + 2 * 192.0));
-        LAUNCHCHK(c, "teco_epilogue", launch_teco_epilogue(d_est_out, d_lr_t, B, H, W, st));
-    }
-    return SR_OK;
-}
-
 int run_step(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, const float* d_est_prev,
              float* d_est_out, float* d_lr_warp, float* d_hr_warp, bool warp_only) {
     // profiling wants each kernel alone on the device; one image cannot be split

@@ -165,7 +165,6 @@ int check_ready(sr_ctx* c, int B);
 // one generator step on device pointers (sr_api.hip); d_est_out / d_lr_warp / d_hr_warp may be nullptr
 int run_step(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, const float* d_est_prev, float* d_est_out,
              float* d_lr_warp, float* d_hr_warp, bool warp_only);
-int run_step_given_flow(sr_ctx* c, int B, const float* d_flow, const float* d_lr_t, const float* d_est_prev, float* d_est_out);
 
 // sr_train.hip
 void train_free(sr_ctx* c);

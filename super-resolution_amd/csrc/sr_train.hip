@@ -24,11 +24,12 @@ struct sr_train_state {
     bool host_stale = false;            // ctx->tensors older than d_params
     ConvLayer fnet_dg[14], srnet_dg[24];   // data-gradient convs of the Conv2D layers (planned where needed)
     std::map<std::string, float*> act;  // saved activations and gradient work buffers
+    std::map<std::string, size_t> act_img;   // floats per image of each (for forwards over a slice of the batch)
     float* part = nullptr;              // wgrad partial sums, one region per layer (reduced together at the end)
     size_t part_bytes = 0;
     // sr_train_clips_grads: frame-major staging, [n zero frames | frames] so that "previous frame" is a pointer offset
     float* clip_lr = nullptr;           // (2 * max_batch) LR frames
-    float* clip_est = nullptr;          // max_batch HR frames: slot f + 1 = the generator's estimate of frame f
+    float* clip_est = nullptr;          // (2 * max_batch) HR frames: n_clips zero frames, then the estimate of every sample
     unsigned char* clip_u8 = nullptr;   // max_batch HR frames as uint8
     double* mse_part = nullptr;
     float* d_loss = nullptr;            // [sr, flow]
@@ -53,6 +54,7 @@ int talloc(sr_ctx* c, const char* name, size_t floats) {
     float* p = nullptr;
     HIPCHK(c, hipMalloc((void**)&p, (floats ? floats : 4) * sizeof(float)));
     c->train->act[name] = p;
+    c->train->act_img[name] = floats / (size_t)c->max_batch;
     return SR_OK;
 }
 
@@ -167,7 +169,8 @@ struct Tape {
     hipStream_t st;
     std::vector<WgradArgs> pending;   // weight gradients whose slice partials wait for reduce_all()
     size_t part_off = 0;
-    float* a(const char* n) { return T->act[n]; }
+    size_t b0 = 0;                    // first image of the slice of the batch this tape works on (forward only)
+    float* a(const char* n) { return T->act[n] + b0 * T->act_img[n]; }
 
     int conv(const ConvLayer& L, const float* in, int H, int W, float* out, int out_cs, int cout_store, int act,
              const float* res, const char* name) {
@@ -424,8 +427,8 @@ int train_backward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const fl
     return t.reduce_all();
 }
 
-// n_clips > 0 (sr_train_clips_grads): est_tm1 is the frame-major estimate buffer whose slots 1.. are still to be
-// made -- after FNet has run on the whole batch, by the frame-by-frame recurrence on the flows it just produced
+// n_clips > 0 (sr_train_clips_grads): est_tm1 is the frame-major estimate buffer, n_clips zero frames followed by room
+// for the estimates of all B samples, which the forward fills frame group by frame group
 int grads_common(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1, const float* hr_t,
                  float* d_grads_out, float* losses, bool dev, int n_clips = 0) {
     int rc = check_ready(c, B);
@@ -450,27 +453,35 @@ int grads_common(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const
     HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, lr_tm1, nlr, kind, st));
     Tape t{c, T, B, c->prec, st};
     if ((rc = train_forward(t, 1, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
+    const float* est_prev_all = c->d_est[0];
+    float* est_all = c->d_est[1];
     if (n_clips > 0) {
-        // no-gradient recurrence (reference FRVSR.py:124-151): frame f's estimate from its flow, its LR frame and
-        // the estimate of frame f - 1, for all clips at once; FNet of (lr_f, lr_f-1) is the pass that just ran
-        float* est = const_cast<float*>(est_tm1);
+        // The no-gradient recurrence (reference FRVSR.py:124-151), est_f = G(lr_f, lr_f-1, est_f-1), IS the training
+        // forward of frame f's samples, so the taped forward runs frame group by frame group (a contiguous slice of
+        // every tape tensor in the frame-major layout) and each group's estimate is the next group's previous
+        // estimate: no separate recurrence.  FNet of all groups is the batched pass that just ran.
+        float* E = const_cast<float*>(est_tm1);          // [n_clips zero frames | estimates of all frames]
         const size_t fl = (size_t)c->h * c->w, fh = fl * 48;
-        for (int f = 0; f + 1 < B / n_clips; ++f) {
+        est_prev_all = E;
+        est_all = E + (size_t)n_clips * fh;
+        for (int f = 0; f < B / n_clips; ++f) {
             const size_t o = (size_t)f * n_clips;
-            if ((rc = run_step_given_flow(c, n_clips, c->d_flow + o * fl * 2, c->d_lr_t + o * fl * 3, est + o * fh, est + (o + n_clips) * fh)))
+            Tape g{c, T, n_clips, c->prec, st};
+            g.b0 = o;
+            if ((rc = train_forward(g, 2, c->d_lr_t + o * fl * 3, c->d_lr_tm1 + o * fl * 3, E + o * fh, E + (o + n_clips) * fh,
+                                    c->d_lr_warp + o * fl * 3, c->d_flow + o * fl * 2)))
                 return rc;
         }
-        HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, kind, st));
     } else {
         HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, kind, cs));
         HIPCHK(c, hipEventRecord(T->ev_est, cs));
         HIPCHK(c, hipStreamWaitEvent(st, T->ev_est, 0));
+        if ((rc = train_forward(t, 2, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
     }
-    if ((rc = train_forward(t, 2, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
     if (hr_t != T->act["hr"]) HIPCHK(c, hipMemcpyAsync(T->act["hr"], hr_t, nhr, kind, cs));
     HIPCHK(c, hipEventRecord(T->ev_hr, cs));
     HIPCHK(c, hipStreamWaitEvent(st, T->ev_hr, 0));
-    if ((rc = train_backward(t, c->d_lr_t, c->d_lr_tm1, c->d_est[0], T->act["hr"], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
+    if ((rc = train_backward(t, c->d_lr_t, c->d_lr_tm1, est_prev_all, T->act["hr"], est_all, c->d_lr_warp, c->d_flow))) return rc;
     if (d_grads_out) HIPCHK(c, hipMemcpyAsync(d_grads_out, T->d_grad, (size_t)T->nparams * 4, hipMemcpyDeviceToDevice, st));
     float l[2] = {0.f, 0.f};
     HIPCHK(c, hipMemcpyAsync(l, T->d_loss, sizeof l, hipMemcpyDeviceToHost, st));
@@ -637,7 +648,7 @@ int sr_train_clips_grads(sr_ctx* c, int n_clips, int c_frames, const void* hr, i
     const size_t fl = (size_t)c->h * c->w * 3, fh = fl * 16;   // floats per LR / HR frame
     if (!T->clip_lr) {
         HIPCHK(c, hipMalloc((void**)&T->clip_lr, 2 * (size_t)c->max_batch * fl * 4));
-        HIPCHK(c, hipMalloc((void**)&T->clip_est, (size_t)c->max_batch * fh * 4));
+        HIPCHK(c, hipMalloc((void**)&T->clip_est, 2 * (size_t)c->max_batch * fh * 4));
         HIPCHK(c, hipMalloc((void**)&T->clip_u8, (size_t)c->max_batch * fh));
     }
     c->clip_active = false;   // the recurrence borrows the ctx's work buffers
