@@ -3,24 +3,31 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload = BASELINE.json configs[1]: 16 synthetic clips x 10 frames, 320x180 LR ->
-1280x720 HR, advanced in lock-step on one MI355X (batch = clips, time = sequential).
-180 rows are zero-padded to 184 (FNet needs multiples of 8),
-the estimate is produced on the 736x1280 grid and only 720 rows count.
-A "step" is one frame of all 16 clips = 16 SR frames.  Inputs are resident in HBM
-before the timed region; the recurrent state never leaves the device.
-For N > 1 (launched by torch.distributed.run) every rank runs its own 16 clips
-(clip sharding, no data-path collective; "weak" scaling) and the time is the MAX
-over ranks between two barriers.
+Workload = BASELINE.json configs[1]: 16 synthetic clips x 10 frames per GPU, 320x180 LR -> 1280x720 HR,
+advanced in lock-step on one MI355X (batch = clips, time = sequential).  180 rows are zero-padded to 184
+(FNet needs multiples of 8), the estimate is produced on the 736x1280 grid and
+only 720 rows count.  A "step" is one frame of all 16 clips = 16 SR frames.  Inputs (synth.synth_clip,
+seed 1000 + global clip id: the clips the parity tests use) are resident in HBM before the timed region;
+the recurrent state never leaves the device.
 
-Default precision is bf16x3: fp32 activations in HBM, every product computed as
-three bf16 MFMAs on hi/lo-split operands with fp32 accumulation.  It meets the
-fp32 parity bar (max-abs <= 1e-3, PSNR delta <= 0.01 dB; tests/test_gpu_step.py).
-Plain bf16 and exact fp32 are measured too and reported under "other_dtypes".
+--gpus N: one process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this
+process is one rank; called plainly with N > 1 it starts the N ranks itself (fresh child processes, before
+anything here touches the GPU) and relays rank 0's JSON line.  Every rank runs its own clips (clip
+sharding, no data-path collective); RCCL carries only the barrier and the MAX over ranks of the time.
+Default: 16 clips per GPU ("weak").  --clips-total C (BASELINE configs[2]: 128): C clips over the N ranks in
+contiguous blocks, each rank advancing its block in lock-step batches of 16 ("strong").
+
+Default precision is bf16x3: fp32 activations in HBM, every product computed as three bf16 MFMAs on
+hi/lo-split operands with fp32 accumulation.  It meets the fp32 parity bar (max-abs <= 1e-3, PSNR delta
+<= 0.01 dB; tests/test_gpu_bench_config.py runs this exact configuration).  Plain bf16 and exact fp32 are
+measured too and reported under "other_dtypes".  After the timed region the first frames of clip 0 are
+compared with the CPU oracle ("verified").
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,68 +40,62 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 H_LR, W_LR, H_PAD = 180, 320, 184
-CLIPS, FRAMES = 16, 10
+BATCH, FRAMES = 16, 10                # clips advanced in lock-step by one context; frames per clip
 FLOP_PER_LR_PX = 2210688.0            # SURVEY.md section 8(d): 1,105,344 MAC per LR pixel per frame
 RES_CONV_FLOP_PER_LR_PX = 73728.0     # one 64->64 3x3 conv: 36,864 MAC per LR pixel
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}   # MI355X_MICROARCH.md dense peaks
+VERIFY_TOL = {"fp32": 1e-3, "bf16x3": 1e-3, "bf16": 0.15}
 
 
-def make_inputs(rank):
-    """[FRAMES, CLIPS, 184, 320, 3] float32 in [0,1], rows 180..183 zero: per clip a smooth random
-    image (bilinear blow-up of coarse noise) drifting by a few pixels per frame, plus fine noise."""
-    lr = np.zeros((FRAMES, CLIPS, H_PAD, W_LR, 3), np.float32)
-    for c in range(CLIPS):
-        rng = np.random.default_rng(1000 * rank + c)
-        coarse = rng.random((H_LR // 12 + 4, W_LR // 12 + 4, 3)).astype(np.float32)
-        big = np.kron(coarse, np.ones((12, 12, 1), np.float32))          # piecewise constant ...
-        k = np.ones(9, np.float32) / 9                                    # ... smoothed by a 9-tap box filter
-        big = np.apply_along_axis(lambda v: np.convolve(v, k, "same"), 0, big)
-        big = np.apply_along_axis(lambda v: np.convolve(v, k, "same"), 1, big)
-        dy, dx = rng.integers(-2, 3, 2)
-        for t in range(FRAMES):
-            oy, ox = 12 + dy * t % 12, 12 + dx * t % 12
-            frame = big[oy:oy + H_LR, ox:ox + W_LR] + 0.05 * rng.standard_normal((H_LR, W_LR, 3)).astype(np.float32)
-            lr[t, c, :H_LR] = np.clip(frame, 0.0, 1.0)
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (nothing in this process has touched
+    the GPU), wait for them, relay rank 0's output.  Returns the exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def make_inputs(first_clip, n_clips):
+    """[FRAMES, n_clips, 184, 320, 3] float32 in [0,1], rows 180..183 zero."""
+    import synth
+    lr = np.zeros((FRAMES, n_clips, H_PAD, W_LR, 3), np.float32)
+    for c in range(n_clips):
+        lr[:, c, :H_LR] = synth.synth_clip(first_clip + c, FRAMES, H_LR, W_LR)
     return lr
 
 
-def make_weights(seed=7):
-    """Seeded random weights in the reference's tensor layout (76 Keras-named tensors; demo.h5 is
-    absent): Glorot-uniform kernels, small biases, the flow head scaled up and the last bias shifted
-    so that flows reach a few tenths of a pixel and outputs spread over [0,1]."""
-    import layers
-    rng = np.random.default_rng(seed)
-    out = {}
-    for i, (name, shape) in enumerate(layers.weight_specs()):
-        if len(shape) == 4:
-            limit = np.sqrt(6.0 / (9 * shape[2] + 9 * shape[3]))
-            w = rng.uniform(-limit, limit, size=shape)
-        else:
-            w = rng.uniform(-0.05, 0.05, size=shape)
-        if i == 26:
-            w = w * 8.0
-        if i == 75:
-            w = w + 0.45
-        out[name] = w.astype(np.float32)
-    return out
-
-
-def run_steps(ctx, lr_dev, n, t0_frame=0):
+def run_steps(ctxs, lr_devs, n, t0_frame=0):
     for i in range(n):
         f = (t0_frame + i) % FRAMES
-        if f == 0:
-            ctx.clip_begin(CLIPS)
-        ctx.clip_push_dev(lr_dev[f].data_ptr())
+        for ctx, lr_dev in zip(ctxs, lr_devs):
+            if f == 0:
+                ctx.clip_begin(BATCH)
+            ctx.clip_push_dev(lr_dev[f].data_ptr())
 
 
-def time_steps(torch, dist, ctx, lr_dev, steps, warmup, world):
-    run_steps(ctx, lr_dev, warmup)
+def time_steps(torch, dist, ctxs, lr_devs, steps, warmup, world):
+    run_steps(ctxs, lr_devs, warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(ctx, lr_dev, steps, t0_frame=warmup)
+    run_steps(ctxs, lr_devs, steps, t0_frame=warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -111,7 +112,7 @@ def kernel_profile(torch, ctx, lr_dev, steps):
     """Per-kernel durations from HIP events recorded on the launch stream."""
     ctx.profile_reset()
     ctx.profile_enable(True)
-    run_steps(ctx, lr_dev, steps)
+    run_steps([ctx], [lr_dev], steps)
     torch.cuda.synchronize()
     prof = ctx.profile_read()
     ctx.profile_enable(False)
@@ -121,41 +122,102 @@ def kernel_profile(torch, ctx, lr_dev, steps):
 def pmc_traffic(dtype):
     """HBM bytes per launch of the res-block conv from the committed PMC passes (counters need
     their own rocprofv3 runs, so they cannot be read live here); None when no pass is on file."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")))
-        tag = {"bf16x3": "conv3x3_lds_kernel<2, 2, 1, true>", "bf16": "conv3x3_lds_kernel<1, 2, 2, true>",
-               "fp32": "conv3x3_lds_kernel<0, 2, 2, true>"}[dtype]
-        best = None
-        for k, v in d["kernels"].items():   # the trunk's grid is the one with the most launches
-            if k.startswith(tag) and (best is None or v["launches"] > best["launches"]):
-                best = v
-        return best["hbm_bytes"] if best else None
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ("r2_hbm_traffic.json", "r1_hbm_traffic.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            tag = d.get("trunk_kernel", {}).get(dtype) or {
+                "bf16x3": "conv3x3_lds_kernel<2, 2, 1, true>", "bf16": "conv3x3_lds_kernel<1, 2, 2, true>",
+                "fp32": "conv3x3_lds_kernel<0, 2, 2, true>"}[dtype]
+            best = None
+            for k, v in d["kernels"].items():   # the trunk's grid is the one with the most launches
+                if k.startswith(tag) and (best is None or v["launches"] > best["launches"]):
+                    best = v
+            if best:
+                return best["hbm_bytes"], name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
-def cpu_baseline(weights, lr):
-    """The torch-CPU restatement (oracle/ref_torch.py; kind 'port': the reference's
-    TF1/Keras path cannot run here) on a bounded sample: 1 clip, 1 warm-up + 3 timed
-    frames at 184x320.  The only place where bench.py touches oracle/."""
+def cpu_baseline(weights, lr0):
+    """The torch-CPU restatement (oracle/ref_torch.py; kind 'port': the reference's TF1/Keras path cannot run
+    here) on a bounded sample of the same workload: clip 0, 184x320, 1 warm-up + 3 timed frames per run,
+    median of 3 runs on all host threads, plus one timed frame on a single thread.  The only place where
+    bench.py touches oracle/; its frames double as the reference of the GPU self-check ("verified")."""
     import torch
     from oracle import ref_torch as rt
     tw = rt.TorchWeights(weights)
-    clip = lr[:4, :1]
-    with torch.no_grad():
-        prev = torch.zeros(1, 3, H_PAD, W_LR)
-        est = torch.zeros(1, 3, 4 * H_PAD, 4 * W_LR)
-        times = []
-        for t in range(4):
-            cur = rt.to_nchw(clip[t])
-            t0 = time.perf_counter()
-            est, _ = rt.generator_step_t(tw, cur, prev, est)
-            times.append(time.perf_counter() - t0)
-            prev = cur
-    dt = float(np.mean(times[1:]))
-    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle/ref_torch.py (torch-CPU fp32, oneDNN), 1 clip, 3 timed frames after 1 warm-up, "
-                      "184x320 -> 736x1280; the reference TF1/Keras CPU path cannot run here"}
+
+    def run(nframes):
+        times, outs = [], []
+        with torch.no_grad():
+            prev = torch.zeros(1, 3, H_PAD, W_LR)
+            est = torch.zeros(1, 3, 4 * H_PAD, 4 * W_LR)
+            for t in range(nframes):
+                cur = rt.to_nchw(lr0[t])
+                t0 = time.perf_counter()
+                est, _ = rt.generator_step_t(tw, cur, prev, est)
+                times.append(time.perf_counter() - t0)
+                outs.append(rt.to_nhwc(est))
+                prev = cur
+        return times, outs
+
+    threads = torch.get_num_threads()
+    rates, frames = [], None
+    for _ in range(3):
+        times, frames = run(4)
+        rates.append(3.0 / sum(times[1:]))
+    torch.set_num_threads(1)
+    t1, _ = run(2)
+    torch.set_num_threads(threads)
+    return {"value": round(float(np.median(rates)), 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "runs": [round(r, 4) for r in rates], "single_thread": round(1.0 / t1[1], 4),
+            "sample": "oracle/ref_torch.py (torch-CPU fp32, oneDNN), clip 0 at 184x320 -> 736x1280: median of 3 runs of "
+                      "1 warm-up + 3 timed frames on all threads; single_thread = 1 timed frame after 1 warm-up; "
+                      "the reference TF1/Keras CPU path cannot run here"}, frames
+
+
+def gpu_first_frames(torch, ctx, lr_dev, n):
+    """Estimates of clip 0 for frames 0..n-1 from a fresh recurrence of the whole batch, [n, 736, 1280, 3]."""
+    out = torch.empty((BATCH, 4 * H_PAD, 4 * W_LR, 3), dtype=torch.float32, device="cuda")
+    ctx.clip_begin(BATCH)
+    got = []
+    for t in range(n):
+        ctx.clip_push_dev(lr_dev[t].data_ptr(), out.data_ptr())
+        torch.cuda.synchronize()
+        got.append(out[0].cpu().numpy())
+    return np.stack(got)
+
+
+def end_to_end(torch, sr_hip, weights, lr, dtype, device, steps):
+    """The reference's own timing bracket (FRVSR.py:292-296: host arrays in, host arrays out) plus its
+    utils.denormalize: every step copies the 16 LR frames (float32, 180 rows: the ctx pads on the device) from
+    page-locked host memory and brings the 16 estimates back as uint8 720p frames, the copy of frame t
+    running under the kernels of frame t+1."""
+    ctx = sr_hip.Context(H_LR, W_LR, max_batch=BATCH, dtype=dtype, device=device, pad=True)
+    ctx.load_weights(weights)
+    lr_host = torch.from_numpy(np.ascontiguousarray(lr[:, :, :H_LR])).pin_memory()
+    outs = [torch.empty((BATCH, 4 * H_LR, 4 * W_LR, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+
+    def run(n, f0=0):
+        for i in range(n):
+            f = (f0 + i) % FRAMES
+            if f == 0:
+                ctx.clip_begin(BATCH)
+            ctx.clip_push_u8(lr_host[f].data_ptr(), outs[i % 2].data_ptr())
+            ctx.u8_wait(1)      # frame i-1 is in host memory: this is where a caller would consume it
+        ctx.u8_wait(0)
+
+    run(FRAMES)
+    ctx.sync()
+    t0 = time.perf_counter()
+    run(steps)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    ctx.close()
+    return {"value": round(BATCH * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps,
+            "what": "per step: 16 LR frames float32 H2D from page-locked memory (11 MB) + generator step + 16 uint8 720p "
+                    "frames D2H (44 MB) on a copy stream; padded 180-row ctx (sr_create_padded + sr_clip_push_u8)"}
 
 
 def train_step_rate(weights, dtype, B=40, h=64, steps=5):
@@ -196,17 +258,42 @@ def train_step_rate(weights, dtype, B=40, h=64, steps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16x3", choices=["fp32", "bf16", "bf16x3"])
-    ap.add_argument("--no-extras", action="store_true", help="skip other dtypes, kernel profile and CPU baseline")
+    ap.add_argument("--clips-total", type=int, default=0,
+                    help="total clips over all ranks (BASELINE configs[2]: 128), in lock-step batches of 16 per rank; "
+                         "default 0 = 16 clips per GPU")
+    ap.add_argument("--no-extras", action="store_true", help="skip other dtypes, kernel profile, end-to-end and CPU baseline")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only (gloo, no GPU): every rank joins, rank 0 prints the rank count; tests the launcher")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
 
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.clips_total and args.clips_total % (world * BATCH):
+        raise SystemExit(f"--clips-total must be a multiple of {BATCH} x the number of GPUs")
+
+    import torch
+    import torch.distributed as dist
+    if args.launch_check:
+        n = world
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            n = int(t.item())
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": n, "world_size_env": world}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libsr_hip has no CPU fallback")
     # one process per GPU; SR_BENCH_BACKEND=gloo lets several ranks rehearse on a one-GPU box
@@ -220,50 +307,65 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import sr_hip
-    weights = make_weights(7)
-    lr = make_inputs(rank)
-    lr_dev = torch.from_numpy(lr).cuda()
+    import synth
+    weights = synth.make_weights(7)
+    per_rank = args.clips_total // world if args.clips_total else BATCH
+    nbatch = per_rank // BATCH
+    lr = make_inputs(rank * per_rank, per_rank)                         # clip ids are global: rank r owns a contiguous block
+    lr_devs = [torch.from_numpy(np.ascontiguousarray(lr[:, b * BATCH:(b + 1) * BATCH])).cuda() for b in range(nbatch)]
     stream = torch.cuda.current_stream().cuda_stream
 
     def make_ctx(dtype):
-        ctx = sr_hip.Context(H_PAD, W_LR, max_batch=CLIPS, dtype=dtype, device=local_rank)
+        ctx = sr_hip.Context(H_PAD, W_LR, max_batch=BATCH, dtype=dtype, device=local_rank)
         ctx.load_weights(weights)
         ctx.set_stream(stream)
         return ctx
 
-    ctx = make_ctx(args.dtype)
-    dt = time_steps(torch, dist, ctx, lr_dev, args.steps, args.warmup, world)
-    frames = world * CLIPS * args.steps
+    ctxs = [make_ctx(args.dtype) for _ in range(nbatch)]
+    dt = time_steps(torch, dist, ctxs, lr_devs, args.steps, args.warmup, world)
+    frames = world * per_rank * args.steps
     fps = frames / dt
     out = {
         "metric": "SR frames/sec (FRVSR x4, 180p->720p)", "value": round(fps, 2), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+        "scaling": "strong" if args.clips_total else "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "FRVSR x4 inference, 16 synthetic clips x 10 frames 320x180 -> 1280x720 per GPU "
-                               "(BASELINE.json configs[1]); LR zero-padded to 184 rows, state resident on device",
-                   "clips_per_gpu": CLIPS, "frames_per_clip": FRAMES, "lr": [H_LR, W_LR], "hr": [720, 1280],
+        "config": {"workload": f"FRVSR x4 inference, {per_rank} synthetic clips x {FRAMES} frames 320x180 -> 1280x720 per GPU "
+                               f"in lock-step batches of {BATCH} (BASELINE.json configs[{2 if args.clips_total else 1}]); "
+                               "LR zero-padded to 184 rows, state resident on device",
+                   "clips_per_gpu": per_rank, "clips_total": world * per_rank, "frames_per_clip": FRAMES,
+                   "lr": [H_LR, W_LR], "hr": [720, 1280], "inputs": "synth.synth_clip(seed 1000 + clip id)",
                    "weights": "seeded random init, demo.h5 tensor layout", "parallelism": f"clip-shard x{world}"},
         "whole_step_tflops": round(fps * FLOP_PER_LR_PX * H_LR * W_LR / 1e12, 2),
     }
+    if world > 1:
+        out["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else 0
+        out["collective_backend"] = dist.get_backend()
 
+    ctx = ctxs[0]
+    for c in ctxs[1:]:
+        c.close()
     if rank == 0 and not args.no_extras:
         # dominant kernel: the 64->64 3x3 res-block conv (20 launches per step, 66.7 % of the FLOPs)
-        prof = kernel_profile(torch, ctx, lr_dev, max(2, min(args.steps, 10)))
+        prof = kernel_profile(torch, ctx, lr_devs[0], max(2, min(args.steps, 10)))
         res = next(p for p in prof if p["name"] == "srnet.res")
+        convs_per_launch = max(1.0, res["flops_per_launch"] / (RES_CONV_FLOP_PER_LR_PX * BATCH * H_PAD * W_LR))
         avg_ms = res["ms_total"] / res["launches"]
-        alg_flops = RES_CONV_FLOP_PER_LR_PX * CLIPS * H_LR * W_LR      # credited on the unpadded 180 rows
+        alg_flops = RES_CONV_FLOP_PER_LR_PX * BATCH * H_LR * W_LR * round(convs_per_launch)   # credited on the unpadded 180 rows
         achieved = alg_flops / (avg_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
-        out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_lds_kernel (srnet.res, 64->64 3x3, 20 launches/step)",
+        traffic, traffic_src = pmc_traffic(args.dtype)
+        out["roofline"] = {"bound": "mfma", "kernel": "srnet.res: the SRNet trunk's 64->64 3x3 convs "
+                                                       f"({round(convs_per_launch)} conv(s) per launch, {res['launches'] // max(1, min(args.steps, 10))} launches/step)",
                            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.dtype),
-                           "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate "
-                                           "passes, profiles/r1_hbm_traffic.json); algorithmic 723 MB",
+                           "frac": round(achieved / peak, 4), "traffic": traffic,
+                           "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, profiles/{traffic_src})",
                            "avg_launch_ms": round(avg_ms, 4), "launches_timed": res["launches"]}
+        nsteps_prof = max(2, min(args.steps, 10))
         tot = sum(p["ms_total"] for p in prof)
-        out["kernel_ms_per_step"] = {p["name"]: round(p["ms_total"] / max(1, res["launches"] // 20), 4) for p in prof}
-        out["kernel_ms_per_step"]["_sum"] = round(tot / max(1, res["launches"] // 20), 4)
+        out["kernel_ms_per_step"] = {p["name"]: round(p["ms_total"] / nsteps_prof, 4) for p in prof}
+        out["kernel_ms_per_step"]["_sum"] = round(tot / nsteps_prof, 4)
         pre = next(p for p in prof if p["name"] == "pre_srnet")
         pre_ms = pre["ms_total"] / pre["launches"]
         out["hbm_kernel"] = {"kernel": "pre_srnet_kernel", "bound": "hbm",
@@ -275,19 +377,32 @@ def main():
             out["hbm_kernel2"] = {"kernel": "tap_gather_kernel (srnet.out)", "bound": "hbm",
                                   "achieved": round(tail["bytes_per_launch"] / (t_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
                                   "unit": "GB/s", "avg_launch_ms": round(t_ms, 4)}
+        if world == 1:
+            gpu_frames = gpu_first_frames(torch, ctx, lr_devs[0], 4)
         ctx.close()
         others = {}
         for d in ("fp32", "bf16", "bf16x3"):
             if d == args.dtype or world > 1:
                 continue
             c2 = make_ctx(d)
-            t2 = time_steps(torch, dist, c2, lr_dev, max(2, args.steps // 2), 2, 1)
-            others[d] = round(CLIPS * max(2, args.steps // 2) / t2, 2)
+            n2 = max(2, args.steps // 4)
+            t2 = time_steps(torch, dist, [c2], lr_devs[:1], n2, 2, 1)
+            others[d] = round(BATCH * n2 / t2, 2)
             c2.close()
         out["other_dtypes"] = {"unit": "frames/s", **others}
         if world == 1:
+            out["end_to_end"] = end_to_end(torch, sr_hip, weights, lr[:, :BATCH], args.dtype, local_rank, max(FRAMES, args.steps // 2))
             out["train_step"] = train_step_rate(weights, args.dtype if args.dtype != "bf16" else "bf16x3")
-            out["cpu_baseline"] = cpu_baseline(weights, lr)
+            out["cpu_baseline"], cpu_frames = cpu_baseline(weights, lr[:, :1])
+            err = float(np.abs(gpu_frames - np.stack([f[0] for f in cpu_frames])).max())
+            out["verified"] = bool(err <= VERIFY_TOL[args.dtype])
+            out["verify"] = {"max_abs_err": round(err, 7), "tol": VERIFY_TOL[args.dtype], "clip": 0, "frames": 4,
+                             "against": "oracle/ref_torch.py frames of the cpu_baseline leg (same inputs, same weights)"}
+            if not out["verified"]:
+                print(json.dumps(out), flush=True)
+                raise SystemExit(f"bench.py: GPU output differs from the CPU oracle by {err:.3e} (> {VERIFY_TOL[args.dtype]})")
+    else:
+        ctx.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

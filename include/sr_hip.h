@@ -60,6 +60,16 @@ int sr_device_count(void);
  * layers.py:31-41), ch == 3, scale == 4; otherwise SR_ERR_SHAPE. */
 int sr_create(sr_ctx** out, int device, int h, int w, int ch, int scale,
               int max_batch, int dtype, int model);
+/* sr_create for LR sizes that are not multiples of 8 (SURVEY.md 8(b) "unless padding mode requested"; the 180-row
+ * frames of BASELINE's 180p -> 720p configs).  The reference itself cannot run such a size: FNet's pooled /
+ * upsampled pyramid comes back 184 rows high and dense_image_warp (layers.py:131) would get mismatched shapes,
+ * and main.py:36-41 only builds square tiles.  Here every tensor the caller passes or receives keeps its own
+ * size (h, w) / (4h, 4w); inside, inputs are zero padded at the bottom / right to the next multiples of 8 and
+ * outputs are cropped: the results are those of the reference graph built at the padded size on zero-padded inputs,
+ * cropped.  The recurrent state of sr_clip_begin / push is kept at the padded size.  Training entry points
+ * refuse such a ctx (SR_ERR_STATE). */
+int sr_create_padded(sr_ctx** out, int device, int h, int w, int ch, int scale,
+                     int max_batch, int dtype, int model);
 int sr_destroy(sr_ctx* ctx);
 
 /* Run the ctx's kernels on this hipStream_t (default: a stream the ctx owns).  A step forks half of
@@ -106,6 +116,18 @@ int sr_step_hr_warp(sr_ctx* ctx, int B, const float* lr_t, const float* lr_tm1,
 int sr_clip_begin(sr_ctx* ctx, int B);
 int sr_clip_push(sr_ctx* ctx, const float* lr_t, float* est_t);
 int sr_clip_push_dev(sr_ctx* ctx, const float* lr_t, float* est_t);
+
+/* The eval loop's output path (reference FRVSR.py:293-351, TecoGAN.py:618-676): predict, then
+ * utils.denormalize = (x * 255).astype(uint8) (utils.py:61-63: truncation, no rounding) before the frame is
+ * written out.  Like sr_clip_push, but the estimate leaves the device as uint8 (B,4h,4w,3) -- a quarter of
+ * the bytes -- into est_u8_host (page-locked memory makes the copy asynchronous), converted on the ctx stream and
+ * copied on a second stream so that the copy of frame t runs under the kernels of frame t+1.  lr_t is a host
+ * pointer (lr_on_device = 0; page-locked for an asynchronous copy) or a device pointer.  The call returns once the
+ * work is enqueued: est_u8_host is complete after sr_u8_wait(ctx, 0) (or sr_sync); sr_u8_wait(ctx, 1) returns
+ * when every frame but the newest has landed -- the pattern is push(t) into buffer t % 2, then
+ * sr_u8_wait(ctx, 1), then consume buffer (t-1) % 2. */
+int sr_clip_push_u8(sr_ctx* ctx, const float* lr_t, int lr_on_device, uint8_t* est_u8_host);
+int sr_u8_wait(sr_ctx* ctx, int keep_in_flight);
 
 /* Replaces fnet.predict (reference FRVSR.py:30, layers.py:15-49):
  * [I_LR_t, I_LR_t_1] (B,h,w,3) each -> flow (B,h,w,2). */

@@ -38,23 +38,29 @@ class FrameRecurrentVideoSR(object):
     def _check_shapes(self):
         if self.lr_shape[0] * 4 != self.hr_shape[0] or self.lr_shape[1] * 4 != self.hr_shape[1]:
             raise ValueError('Incompatible resolutions with upscale x4.')
-        if self.lr_shape[0] % 8 or self.lr_shape[1] % 8:
+        if (self.lr_shape[0] % 8 or self.lr_shape[1] % 8) and not self._pad_to_8():
             raise ValueError('low resolution height and width must be multiples of 8 '
-                             '(FNet pools 3x and upsamples 3x; reference layers.py:31-41)')
+                             '(FNet pools 3x and upsamples 3x; reference layers.py:31-41); '
+                             'data.pad_to_8: true pads inside the native context (inference only)')
+
+    def _pad_to_8(self):
+        data = self.configs.get('data') if isinstance(self.configs, dict) else None
+        return bool(data and data.get('pad_to_8'))
 
     def build(self):
         self._check_shapes()
         dtype = (self.configs.get('dtype') or 'fp32') if isinstance(self.configs, dict) else 'fp32'
         device = int(os.environ.get('LOCAL_RANK', '0'))
-        self.core = GeneratorCore(self.lr_shape, model=self.model_kind, dtype=dtype, device=device)
+        pad = self._pad_to_8() and bool(self.lr_shape[0] % 8 or self.lr_shape[1] % 8)
+        self.core = GeneratorCore(self.lr_shape, model=self.model_kind, dtype=dtype, device=device, pad=pad)
         print('[INFO] Creating FNet ...')
         self.fnet = FNet(self.lr_shape, core=self.core).build()
         print('[INFO] Creating SRNet ...')
         self.srnet = SRNet(self.lr_shape, core=self.core).build()
-        self.upscaling = Upscaling(self.lr_shape).build()
-        self.hr_warp = Warp(self.hr_shape, 1).build()
-        self.lr_warp = Warp(self.lr_shape, 2).build()
-        self.space2depth = Space2Depth(self.hr_shape).build()
+        self.upscaling = Upscaling(self.lr_shape, device=device).build()
+        self.hr_warp = Warp(self.hr_shape, 1, device=device).build()
+        self.lr_warp = Warp(self.lr_shape, 2, device=device).build()
+        self.space2depth = Space2Depth(self.hr_shape, device=device).build()
         self.frvsr = GeneratorModel(self.core, 'FRVSR')
         # loss functions and learning rate of the reference (FRVSR.py:69-71)
         self.opt = Adam(lr=1e-4)

@@ -17,7 +17,7 @@ class TecoGAN(FrameRecurrentVideoSR):
 
     def build(self):
         super().build()
-        self.bicubic_upscale = Upscaling(self.lr_shape, 1).build()
+        self.bicubic_upscale = Upscaling(self.lr_shape, 1, device=self.core.device).build()
         self.generator = GeneratorModel(self.core, 'Generator')
         self.hr_warping = HRWarpingModel(self.core)
         self.opt = Adam(lr=5e-5)                                    # TecoGAN.py:110-113

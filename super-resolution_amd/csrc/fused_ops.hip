@@ -463,6 +463,69 @@ hipError_t launch_u8_normalize(const unsigned char* in, float* out, size_t n, hi
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ pad mode + uint8 output
+__global__ void pad_copy_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int rows, int cols, int ch,
+                                int rows_p, int cols_p) {
+    const long total = (long)B * rows_p * cols_p * ch;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int e = idx % (cols_p * ch);
+    long q = idx / (cols_p * ch);
+    const int y = q % rows_p;
+    const int b = q / rows_p;
+    out[idx] = (y < rows && e < cols * ch) ? in[((size_t)b * rows + y) * cols * ch + e] : 0.f;
+}
+
+__global__ void crop_copy_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int rows, int cols, int ch,
+                                 int rows_p, int cols_p) {
+    const long total = (long)B * rows * cols * ch;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int e = idx % (cols * ch);
+    long q = idx / (cols * ch);
+    const int y = q % rows;
+    const int b = q / rows;
+    out[idx] = in[((size_t)b * rows_p + y) * cols_p * ch + e];
+}
+
+hipError_t launch_pad_copy(const float* in, float* out, int B, int rows, int cols, int ch, int rows_p, int cols_p, hipStream_t s) {
+    const long total = (long)B * rows_p * cols_p * ch;
+    hipLaunchKernelGGL(pad_copy_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, in, out, B, rows, cols, ch, rows_p, cols_p);
+    return hipGetLastError();
+}
+
+hipError_t launch_crop_copy(const float* in, float* out, int B, int rows, int cols, int ch, int rows_p, int cols_p, hipStream_t s) {
+    const long total = (long)B * rows * cols * ch;
+    hipLaunchKernelGGL(crop_copy_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, in, out, B, rows, cols, ch, rows_p, cols_p);
+    return hipGetLastError();
+}
+
+// 4 floats -> 4 bytes per thread; row_elems (= 4w * 3) is a multiple of 4
+__global__ void denorm_u8_kernel(const float* __restrict__ est, unsigned char* __restrict__ out, int B, int HH, int row4, int rows) {
+    const long total = (long)B * rows * row4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int e = idx % row4;
+    long q = idx / row4;
+    const int y = q % rows;
+    const int b = q / rows;
+    const float4 v = reinterpret_cast<const float4*>(est)[((size_t)b * HH + y) * row4 + e];
+    // numpy's float32 -> uint8 cast truncates toward zero and wraps modulo 256
+    uchar4 o;
+    o.x = (unsigned char)(int)(v.x * 255.0f);
+    o.y = (unsigned char)(int)(v.y * 255.0f);
+    o.z = (unsigned char)(int)(v.z * 255.0f);
+    o.w = (unsigned char)(int)(v.w * 255.0f);
+    reinterpret_cast<uchar4*>(out)[idx] = o;
+}
+
+hipError_t launch_denorm_u8(const float* est, unsigned char* out, int B, int HH, int row_elems, int rows, hipStream_t s) {
+    if (row_elems % 4) return hipErrorInvalidValue;
+    const long total = (long)B * rows * (row_elems / 4);
+    hipLaunchKernelGGL(denorm_u8_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, est, out, B, HH, row_elems / 4, rows);
+    return hipGetLastError();
+}
+
 hipError_t launch_blur_cubic_down4(const float* hr, float* lr, int N, int H, int W, int C, hipStream_t s) {
     const long total = (long)N * (H / 4) * (W / 4) * C;
     hipLaunchKernelGGL(blur_cubic_down4_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, hr, lr, N, H, W, C);

@@ -543,6 +543,44 @@ int run_step(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, const
     return SR_OK;
 }
 
+// ---------------------------------------------------------------- caller tensors <-> kernel tensors
+// The caller's tensors are dense (B, scale*h_in, scale*w_in, ch); the kernels' are (B, scale*h, scale*w, ch).  They
+// are the same thing unless the ctx was made by sr_create_padded for a size that is not a multiple of 8: then
+// inputs are zero padded at the bottom / right on the way in and outputs cropped on the way out (host tensors
+// through a dense device staging buffer; stream order makes one buffer per size class enough).
+int put_in(sr_ctx* c, float* d_dst, const float* src, bool src_dev, int B, int scale, int ch) {
+    hipStream_t st = c->stream;
+    const int rows = scale * c->h_in, cols = scale * c->w_in;
+    const size_t n = (size_t)B * rows * cols * ch * 4;
+    if (!c->pad) {
+        HIPCHK(c, hipMemcpyAsync(d_dst, src, n, src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        return SR_OK;
+    }
+    const float* dsrc = src;
+    if (!src_dev) {
+        float* stage = (size_t)rows * cols * ch > (size_t)c->h_in * c->w_in * 3 ? c->d_io_hr : c->d_io_lr;
+        HIPCHK(c, hipMemcpyAsync(stage, src, n, hipMemcpyHostToDevice, st));
+        dsrc = stage;
+    }
+    LAUNCHCHK(c, "pad_copy", launch_pad_copy(dsrc, d_dst, B, rows, cols, ch, scale * c->h, scale * c->w, st));
+    return SR_OK;
+}
+
+int get_out(sr_ctx* c, float* dst, bool dst_dev, const float* d_src, int B, int scale, int ch) {
+    hipStream_t st = c->stream;
+    const int rows = scale * c->h_in, cols = scale * c->w_in;
+    const size_t n = (size_t)B * rows * cols * ch * 4;
+    if (!c->pad) {
+        HIPCHK(c, hipMemcpyAsync(dst, d_src, n, dst_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+        return SR_OK;
+    }
+    float* stage = (size_t)rows * cols * ch > (size_t)c->h_in * c->w_in * 3 ? c->d_io_hr : c->d_io_lr;
+    float* ddst = dst_dev ? dst : stage;
+    LAUNCHCHK(c, "crop_copy", launch_crop_copy(d_src, ddst, B, rows, cols, ch, scale * c->h, scale * c->w, st));
+    if (!dst_dev) HIPCHK(c, hipMemcpyAsync(dst, stage, n, hipMemcpyDeviceToHost, st));
+    return SR_OK;
+}
+
 }  // namespace srh
 
 using namespace srh;
@@ -558,14 +596,17 @@ int sr_device_count(void) {
     return n;
 }
 
-int sr_create(sr_ctx** out, int device, int h, int w, int ch, int scale, int max_batch, int dtype, int model) {
+static int create_common(sr_ctx** out, int device, int h_in, int w_in, int ch, int scale, int max_batch, int dtype, int model,
+                         bool allow_pad) {
     if (!out) return fail(nullptr, SR_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (ch != 3) return fail(nullptr, SR_ERR_SHAPE, "channels must be 3, got %d", ch);
     if (scale != 4) return fail(nullptr, SR_ERR_SHAPE, "upscale must be 4, got %d", scale);
-    if (h < 8 || w < 8 || h % 8 || w % 8)
+    if (!allow_pad && (h_in < 8 || w_in < 8 || h_in % 8 || w_in % 8))
         return fail(nullptr, SR_ERR_SHAPE, "LR tile %dx%d: height and width must be multiples of 8 "
-                    "(FNet pools 3x and upsamples 3x; reference layers.py:31-41)", h, w);
+                    "(FNet pools 3x and upsamples 3x; reference layers.py:31-41); sr_create_padded pads for you", h_in, w_in);
+    if (h_in < 2 || w_in < 2) return fail(nullptr, SR_ERR_SHAPE, "LR tile %dx%d: dense_image_warp needs at least 2x2", h_in, w_in);
+    const int h = round_up(h_in, 8), w = round_up(w_in, 8);
     if (max_batch < 1) return fail(nullptr, SR_ERR_ARG, "max_batch must be >= 1");
     if (dtype < 0 || dtype > 2) return fail(nullptr, SR_ERR_ARG, "dtype must be 0 (fp32), 1 (bf16) or 2 (bf16x3)");
     if (model != SR_FRVSR && model != SR_TECOGAN) return fail(nullptr, SR_ERR_ARG, "model must be 0 (frvsr) or 1 (tecogan)");
@@ -579,6 +620,9 @@ int sr_create(sr_ctx** out, int device, int h, int w, int ch, int scale, int max
     c->device = device;
     c->h = h;
     c->w = w;
+    c->h_in = h_in;
+    c->w_in = w_in;
+    c->pad = h != h_in || w != w_in;
     c->max_batch = max_batch;
     c->prec = dtype;
     c->model = model;
@@ -617,8 +661,21 @@ int sr_create(sr_ctx** out, int device, int h, int w, int ch, int scale, int max
         if (hipMalloc((void**)p.p, B * p.elems * 4) != hipSuccess)
             return bail(fail(c, SR_ERR_HIP, "hipMalloc of %zu bytes failed", B * p.elems * 4));
     }
+    if (c->pad) {   // caller-shaped staging for host <-> device copies
+        const size_t n = B * (size_t)h_in * w_in * 48 * 4;
+        if (hipMalloc((void**)&c->d_io_hr, n) != hipSuccess || hipMalloc((void**)&c->d_io_lr, n / 16) != hipSuccess)
+            return bail(fail(c, SR_ERR_HIP, "hipMalloc of %zu bytes failed", n));
+    }
     *out = c;
     return SR_OK;
+}
+
+int sr_create(sr_ctx** out, int device, int h, int w, int ch, int scale, int max_batch, int dtype, int model) {
+    return create_common(out, device, h, w, ch, scale, max_batch, dtype, model, false);
+}
+
+int sr_create_padded(sr_ctx** out, int device, int h, int w, int ch, int scale, int max_batch, int dtype, int model) {
+    return create_common(out, device, h, w, ch, scale, max_batch, dtype, model, true);
 }
 
 int sr_destroy(sr_ctx* c) {
@@ -637,9 +694,19 @@ int sr_destroy(sr_ctx* c) {
     train_free(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto& kv : c->buf) (void)hipFree(kv.second);
-    float* fl[] = {c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_flow, c->d_lr_warp, c->d_hr_warp, c->d_ss};
+    float* fl[] = {c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_flow, c->d_lr_warp, c->d_hr_warp, c->d_ss,
+                   c->d_io_lr, c->d_io_hr};
     for (auto p : fl)
         if (p) (void)hipFree(p);
+    if (c->copy_stream) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamDestroy(c->copy_stream);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (c->d_u8[i]) (void)hipFree(c->d_u8[i]);
+        if (c->ev_u8_ready[i]) (void)hipEventDestroy(c->ev_u8_ready[i]);
+        if (c->ev_u8_done[i]) (void)hipEventDestroy(c->ev_u8_done[i]);
+    }
     for (auto& L : c->fnet) free_layer(L);
     for (auto& L : c->srnet) free_layer(L);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -661,6 +728,7 @@ int sr_sync(sr_ctx* c) {
     if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     return SR_OK;
 }
 
@@ -747,7 +815,15 @@ int sr_step_dev(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const 
     int rc = check_ready(c, B);
     if (rc) return rc;
     if (!lr_t || !lr_tm1 || !est_tm1 || !est_t) return fail(c, SR_ERR_ARG, "NULL tensor pointer");
-    return run_step(c, B, lr_t, lr_tm1, est_tm1, est_t, lr_warp, nullptr, false);
+    if (!c->pad) return run_step(c, B, lr_t, lr_tm1, est_tm1, est_t, lr_warp, nullptr, false);
+    c->clip_active = false;   // pad mode borrows the state buffers as the padded tensors
+    if ((rc = put_in(c, c->d_lr_t, lr_t, true, B, 1, 3)) || (rc = put_in(c, c->d_lr_tm1, lr_tm1, true, B, 1, 3)) ||
+        (rc = put_in(c, c->d_est[0], est_tm1, true, B, 4, 3)))
+        return rc;
+    rc = run_step(c, B, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], lr_warp ? c->d_lr_warp : nullptr, nullptr, false);
+    if (rc) return rc;
+    if ((rc = get_out(c, est_t, true, c->d_est[1], B, 4, 3))) return rc;
+    return lr_warp ? get_out(c, lr_warp, true, c->d_lr_warp, B, 1, 3) : SR_OK;
 }
 
 int sr_step(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1, float* est_t, float* lr_warp) {
@@ -755,15 +831,14 @@ int sr_step(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const floa
     if (rc) return rc;
     if (!lr_t || !lr_tm1 || !est_tm1 || !est_t) return fail(c, SR_ERR_ARG, "NULL tensor pointer");
     c->clip_active = false;   // the stateless step borrows the state buffers
-    const size_t nlr = (size_t)B * c->h * c->w * 3 * 4, nhr = nlr * 16;
     hipStream_t st = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, lr_tm1, nlr, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, hipMemcpyHostToDevice, st));
+    if ((rc = put_in(c, c->d_lr_t, lr_t, false, B, 1, 3)) || (rc = put_in(c, c->d_lr_tm1, lr_tm1, false, B, 1, 3)) ||
+        (rc = put_in(c, c->d_est[0], est_tm1, false, B, 4, 3)))
+        return rc;
     rc = run_step(c, B, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], lr_warp ? c->d_lr_warp : nullptr, nullptr, false);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(est_t, c->d_est[1], nhr, hipMemcpyDeviceToHost, st));
-    if (lr_warp) HIPCHK(c, hipMemcpyAsync(lr_warp, c->d_lr_warp, nlr, hipMemcpyDeviceToHost, st));
+    if ((rc = get_out(c, est_t, false, c->d_est[1], B, 4, 3))) return rc;
+    if (lr_warp && (rc = get_out(c, lr_warp, false, c->d_lr_warp, B, 1, 3))) return rc;
     HIPCHK(c, hipStreamSynchronize(st));
     return SR_OK;
 }
@@ -773,14 +848,13 @@ int sr_step_hr_warp(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, co
     if (rc) return rc;
     if (!lr_t || !lr_tm1 || !est_tm1 || !hr_warp) return fail(c, SR_ERR_ARG, "NULL tensor pointer");
     c->clip_active = false;
-    const size_t nlr = (size_t)B * c->h * c->w * 3 * 4, nhr = nlr * 16;
     hipStream_t st = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, lr_tm1, nlr, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, hipMemcpyHostToDevice, st));
+    if ((rc = put_in(c, c->d_lr_t, lr_t, false, B, 1, 3)) || (rc = put_in(c, c->d_lr_tm1, lr_tm1, false, B, 1, 3)) ||
+        (rc = put_in(c, c->d_est[0], est_tm1, false, B, 4, 3)))
+        return rc;
     rc = run_step(c, B, c->d_lr_t, c->d_lr_tm1, c->d_est[0], nullptr, nullptr, c->d_hr_warp, true);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(hr_warp, c->d_hr_warp, nhr, hipMemcpyDeviceToHost, st));
+    if ((rc = get_out(c, hr_warp, false, c->d_hr_warp, B, 4, 3))) return rc;
     HIPCHK(c, hipStreamSynchronize(st));
     return SR_OK;
 }
@@ -798,43 +872,89 @@ int sr_clip_begin(sr_ctx* c, int B) {
     return SR_OK;
 }
 
-static int clip_push_common(sr_ctx* c, const float* lr_t, float* est_t, bool dev) {
+static int clip_push_common(sr_ctx* c, const float* lr_t, float* est_t, bool dev, bool sync) {
     if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
     if (!c->clip_active) return fail(c, SR_ERR_STATE, "sr_clip_push without sr_clip_begin");
     if (!lr_t) return fail(c, SR_ERR_ARG, "lr_t is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     const int B = c->clip_B;
-    const size_t nlr = (size_t)B * c->h * c->w * 3 * 4, nhr = nlr * 16;
     hipStream_t st = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    int rc = put_in(c, c->d_lr_t, lr_t, dev, B, 1, 3);
+    if (rc) return rc;
     float* out = c->d_est[c->cur ^ 1];
-    int rc = run_step(c, B, c->d_lr_t, c->d_lr_tm1, c->d_est[c->cur], out, nullptr, nullptr, false);
+    rc = run_step(c, B, c->d_lr_t, c->d_lr_tm1, c->d_est[c->cur], out, nullptr, nullptr, false);
     if (rc) return rc;
     // est state := output, prev LR := current (reference FRVSR.py:293,309)
     c->cur ^= 1;
     float* t = c->d_lr_t;
     c->d_lr_t = c->d_lr_tm1;
     c->d_lr_tm1 = t;
-    if (est_t) HIPCHK(c, hipMemcpyAsync(est_t, out, nhr, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
-    if (!dev) HIPCHK(c, hipStreamSynchronize(st));
+    if (est_t && (rc = get_out(c, est_t, dev, out, B, 4, 3))) return rc;
+    if (sync) HIPCHK(c, hipStreamSynchronize(st));
     return SR_OK;
 }
 
-int sr_clip_push(sr_ctx* c, const float* lr_t, float* est_t) { return clip_push_common(c, lr_t, est_t, false); }
-int sr_clip_push_dev(sr_ctx* c, const float* lr_t, float* est_t) { return clip_push_common(c, lr_t, est_t, true); }
+int sr_clip_push(sr_ctx* c, const float* lr_t, float* est_t) { return clip_push_common(c, lr_t, est_t, false, true); }
+int sr_clip_push_dev(sr_ctx* c, const float* lr_t, float* est_t) { return clip_push_common(c, lr_t, est_t, true, false); }
+
+int sr_clip_push_u8(sr_ctx* c, const float* lr_t, int lr_on_device, uint8_t* est_u8_host) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    if (!est_u8_host) return fail(c, SR_ERR_ARG, "est_u8_host is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->copy_stream) {   // first use: the copy stream, two device frames and their events
+        const size_t n = (size_t)c->max_batch * 16 * c->h_in * c->w_in * 3;
+        bool ok = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < 2 && ok; ++i)
+            ok = hipMalloc((void**)&c->d_u8[i], n) == hipSuccess &&
+                 hipEventCreateWithFlags(&c->ev_u8_ready[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&c->ev_u8_done[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) return fail(c, SR_ERR_HIP, "uint8 output path: stream / buffer / event creation failed");
+    }
+    if (!c->clip_active) return fail(c, SR_ERR_STATE, "sr_clip_push_u8 without sr_clip_begin");
+    int rc = clip_push_common(c, lr_t, nullptr, lr_on_device != 0, false);   // no fp32 copy out, no synchronisation
+    if (rc) return rc;
+    const int B = c->clip_B, slot = (int)(c->u8_pushes & 1);
+    const float* est = c->d_est[c->cur];   // the estimate this push produced (state already swapped)
+    hipStream_t st = c->stream;
+    if (c->u8_pushes >= 2) HIPCHK(c, hipStreamWaitEvent(st, c->ev_u8_done[slot], 0));   // frame n-2 has left this slot
+    LAUNCHCHK(c, "denorm_u8", launch_denorm_u8(est, c->d_u8[slot], B, 4 * c->h, 4 * c->w * 3, 4 * c->h_in, st));
+    HIPCHK(c, hipEventRecord(c->ev_u8_ready[slot], st));
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_u8_ready[slot], 0));
+    // rows are cropped by the kernel; columns only when the width was padded (then row by row)
+    const size_t row = (size_t)4 * c->w_in * 3, rows = (size_t)B * 4 * c->h_in;
+    if (c->w == c->w_in)
+        HIPCHK(c, hipMemcpyAsync(est_u8_host, c->d_u8[slot], rows * row, hipMemcpyDeviceToHost, c->copy_stream));
+    else
+        HIPCHK(c, hipMemcpy2DAsync(est_u8_host, row, c->d_u8[slot], (size_t)4 * c->w * 3, row, rows, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->ev_u8_done[slot], c->copy_stream));
+    ++c->u8_pushes;
+    return SR_OK;
+}
+
+int sr_u8_wait(sr_ctx* c, int keep_in_flight) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    if (!c->copy_stream || c->u8_pushes == 0) return SR_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t n = c->u8_pushes;
+    if (keep_in_flight >= 1) {   // everything but the newest frame
+        if (n >= 2) HIPCHK(c, hipEventSynchronize(c->ev_u8_done[(n - 2) & 1]));
+        return SR_OK;
+    }
+    HIPCHK(c, hipEventSynchronize(c->ev_u8_done[(n - 1) & 1]));
+    if (n >= 2) HIPCHK(c, hipEventSynchronize(c->ev_u8_done[(n - 2) & 1]));
+    return SR_OK;
+}
 
 int sr_fnet(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, float* flow) {
     int rc = check_ready(c, B);
     if (rc) return rc;
     if (!lr_t || !lr_tm1 || !flow) return fail(c, SR_ERR_ARG, "NULL tensor pointer");
     c->clip_active = false;
-    const size_t nlr = (size_t)B * c->h * c->w * 3 * 4;
     hipStream_t st = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, lr_tm1, nlr, hipMemcpyHostToDevice, st));
+    if ((rc = put_in(c, c->d_lr_t, lr_t, false, B, 1, 3)) || (rc = put_in(c, c->d_lr_tm1, lr_tm1, false, B, 1, 3))) return rc;
     rc = run_fnet(c, B, c->d_lr_t, c->d_lr_tm1, c->d_flow);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(flow, c->d_flow, nlr / 3 * 2, hipMemcpyDeviceToHost, st));
+    if ((rc = get_out(c, flow, false, c->d_flow, B, 1, 2))) return rc;
     HIPCHK(c, hipStreamSynchronize(st));
     return SR_OK;
 }
@@ -844,14 +964,12 @@ int sr_srnet(sr_ctx* c, int B, const float* lr_t, const float* s_s, float* out) 
     if (rc) return rc;
     if (!lr_t || !s_s || !out) return fail(c, SR_ERR_ARG, "NULL tensor pointer");
     c->clip_active = false;
-    const size_t nlr = (size_t)B * c->h * c->w * 3 * 4, nhr = nlr * 16;
     hipStream_t st = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_ss, s_s, nhr, hipMemcpyHostToDevice, st));
+    if ((rc = put_in(c, c->d_lr_t, lr_t, false, B, 1, 3)) || (rc = put_in(c, c->d_ss, s_s, false, B, 1, 48))) return rc;
     LAUNCHCHK(c, "srnet.input", launch_srnet_input(c->d_lr_t, c->d_ss, c->buf["s_in"], c->prec == P_BF16, B, c->h, c->w, st));
     rc = run_srnet(c, B, c->d_est[1]);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(out, c->d_est[1], nhr, hipMemcpyDeviceToHost, st));
+    if ((rc = get_out(c, out, false, c->d_est[1], B, 4, 3))) return rc;
     HIPCHK(c, hipStreamSynchronize(st));
     return SR_OK;
 }

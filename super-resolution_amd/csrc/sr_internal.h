@@ -59,6 +59,16 @@ inline size_t round_up_sz(size_t v, size_t m = 256) { return (v + m - 1) / m * m
 
 struct sr_ctx {
     int device = 0, h = 0, w = 0, max_batch = 0, prec = sr::P_FP32, model = SR_FRVSR;
+    // pad mode (sr_create_padded): the caller's tensors are (h_in, w_in); the kernels run on (h, w) = both rounded
+    // up to multiples of 8, zero padded at the bottom / right, outputs cropped.  h_in == h, w_in == w otherwise.
+    int h_in = 0, w_in = 0;
+    bool pad = false;
+    float *d_io_lr = nullptr, *d_io_hr = nullptr;   // dense caller-shaped staging for host <-> device copies (pad mode)
+    // uint8 output path (sr_clip_push_u8): two device frames, converted on `stream`, copied out on `copy_stream`
+    hipStream_t copy_stream = nullptr;
+    unsigned char* d_u8[2] = {nullptr, nullptr};
+    hipEvent_t ev_u8_ready[2] = {nullptr, nullptr}, ev_u8_done[2] = {nullptr, nullptr};
+    int64_t u8_pushes = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;

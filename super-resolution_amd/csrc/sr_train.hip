@@ -433,6 +433,7 @@ int grads_common(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const
                  float* d_grads_out, float* losses, bool dev, int n_clips = 0) {
     int rc = check_ready(c, B);
     if (rc) return rc;
+    if (c->pad) return fail(c, SR_ERR_STATE, "training needs a ctx whose tile size is a multiple of 8 (sr_create, not sr_create_padded)");
     if (!lr_t || !lr_tm1 || !est_tm1 || !hr_t) return fail(c, SR_ERR_ARG, "NULL tensor pointer");
     if ((rc = train_init(c))) {
         train_free(c);   // a half-built state must not survive
@@ -640,6 +641,7 @@ int sr_train_clips_grads(sr_ctx* c, int n_clips, int c_frames, const void* hr, i
     const int B = n_clips * c_frames;
     int rc = check_ready(c, B);
     if (rc) return rc;
+    if (c->pad) return fail(c, SR_ERR_STATE, "training needs a ctx whose tile size is a multiple of 8 (sr_create, not sr_create_padded)");
     if ((rc = train_init(c))) {
         train_free(c);
         return rc;

@@ -63,13 +63,15 @@ def glorot_init(seed=None):
 class GeneratorCore:
     """Weights + native context of one generator (FNet + SRNet + warps) for one LR tile shape."""
 
-    def __init__(self, lr_shape, model="frvsr", dtype="fp32", device=0, seed=None):
+    def __init__(self, lr_shape, model="frvsr", dtype="fp32", device=0, seed=None, pad=False):
+        """pad: LR height / width need not be multiples of 8 (sr_create_padded: zero padding inside the native
+        context, outputs cropped; inference only)."""
         h, w, c = (int(v) for v in lr_shape)
         if c != 3:
             raise ValueError(f"generator expects 3 channels, got {c}")
         self.lr_shape = (h, w, c)
         self.hr_shape = (4 * h, 4 * w, c)
-        self.model, self.dtype, self.device = model, dtype, device
+        self.model, self.dtype, self.device, self.pad = model, dtype, device, bool(pad)
         self.tensors = glorot_init(seed)      # [(keras_name, array)] in file order
         self._ctx = None
         self._ctx_batch = 0
@@ -123,7 +125,7 @@ class GeneratorCore:
                 self._ctx.close()
             h, w, _ = self.lr_shape
             self._ctx = sr_hip.Context(h, w, max_batch=int(batch), dtype=self.dtype, model=self.model,
-                                       device=self.device)
+                                       device=self.device, pad=self.pad)
             self._ctx_batch = int(batch)
             self._ctx.load_weights(self.tensors)
         return self._ctx
@@ -262,32 +264,36 @@ class SRNet(object):
         return SRNetModel(self._core or GeneratorCore(self.lr_shape))
 
 
+# the weight-free blocks take an optional device= (the GPU of this process' rank; the reference has one device)
 class Upscaling(object):
-    def __init__(self, LR_shape, idx=0):
+    def __init__(self, LR_shape, idx=0, device=0):
         self.lr_shape = LR_shape
         self.idx = idx
+        self.device = device
 
     def build(self):
-        return UpscalingModel(self.idx)
+        return UpscalingModel(self.idx, device=self.device)
 
 
 class Space2Depth(object):
-    def __init__(self, HR_shape):
+    def __init__(self, HR_shape, device=0):
         self.hr_shape = HR_shape
+        self.device = device
 
     def build(self):
         if self.hr_shape[0] % 4 or self.hr_shape[1] % 4:
             raise ValueError("Space2Depth: HR height and width must be multiples of 4")
-        return Space2DepthModel()
+        return Space2DepthModel(device=self.device)
 
 
 class Warp(object):
-    def __init__(self, input_shape, idx):
+    def __init__(self, input_shape, idx, device=0):
         self.input_shape = input_shape
         self.idx = idx
+        self.device = device
 
     def build(self):
-        return WarpModel(self.idx)
+        return WarpModel(self.idx, device=self.device)
 
 
 class Adam(object):
@@ -385,7 +391,14 @@ class GeneratorModel(_CoreModel):
         self._clip_ctx.clip_begin(batch)
 
     def clip_push(self, lr_t, want_output=True):
-        return self._clip_ctx.clip_push(lr_t, want_output=want_output)
+        ctx = getattr(self, "_clip_ctx", None)
+        if ctx is None:
+            raise RuntimeError("clip_push without clip_begin")
+        if ctx is not self.core._ctx or not ctx._h:
+            # a larger predict / train batch rebuilt the native context: the recurrent state went with the old one
+            raise RuntimeError("the native context was rebuilt for a larger batch since clip_begin: "
+                               "call clip_begin again (the recurrent state restarts from zero)")
+        return ctx.clip_push(lr_t, want_output=want_output)
 
 
 class HRWarpingModel(_CoreModel):

@@ -27,6 +27,7 @@ SIGNATURES = {
     "sr_last_error": (C.c_char_p, [_vp]),
     "sr_device_count": (C.c_int, []),
     "sr_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sr_create_padded": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sr_destroy": (C.c_int, [_vp]),
     "sr_set_stream": (C.c_int, [_vp, _vp]),
     "sr_sync": (C.c_int, [_vp]),
@@ -39,6 +40,8 @@ SIGNATURES = {
     "sr_clip_begin": (C.c_int, [_vp, C.c_int]),
     "sr_clip_push": (C.c_int, [_vp, _vp, _vp]),
     "sr_clip_push_dev": (C.c_int, [_vp, _vp, _vp]),
+    "sr_clip_push_u8": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "sr_u8_wait": (C.c_int, [_vp, C.c_int]),
     "sr_fnet": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "sr_srnet": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "sr_profile_enable": (C.c_int, [_vp, C.c_int]),
@@ -119,12 +122,15 @@ def device_count() -> int:
 class Context:
     """One generator (FNet + SRNet + warps) for LR tiles of (h, w, 3) on one GPU."""
 
-    def __init__(self, h, w, ch=3, scale=4, max_batch=1, dtype="fp32", model="frvsr", device=0):
+    def __init__(self, h, w, ch=3, scale=4, max_batch=1, dtype="fp32", model="frvsr", device=0, pad=False):
+        """pad=True: h, w need not be multiples of 8 (sr_create_padded: zero padding inside, outputs cropped)."""
         self.h, self.w, self.max_batch = int(h), int(w), int(max_batch)
         self.dtype = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
         self.model = {"frvsr": FRVSR, "tecogan": TECOGAN}[model] if isinstance(model, str) else int(model)
+        self.device = int(device)
         self._h = _vp()
-        _check(lib().sr_create(C.byref(self._h), device, h, w, ch, scale, max_batch, self.dtype, self.model))
+        create = lib().sr_create_padded if pad else lib().sr_create
+        _check(create(C.byref(self._h), device, h, w, ch, scale, max_batch, self.dtype, self.model))
 
     # -- lifetime
     def close(self):
@@ -216,6 +222,14 @@ class Context:
 
     def clip_push_dev(self, lr_t, est_t=None):
         _check(lib().sr_clip_push_dev(self._h, _vp(lr_t), _vp(est_t) if est_t else None), self._h)
+
+    def clip_push_u8(self, lr_t, out_u8, lr_on_device=False):
+        """Asynchronous: lr_t / out_u8 are raw pointers (ints) -- a device or page-locked host LR frame batch and a
+        (page-locked) host uint8 buffer of (B,4h,4w,3).  Complete after u8_wait(0) / sync()."""
+        _check(lib().sr_clip_push_u8(self._h, _vp(lr_t), int(bool(lr_on_device)), _vp(out_u8)), self._h)
+
+    def u8_wait(self, keep_in_flight=0):
+        _check(lib().sr_u8_wait(self._h, int(keep_in_flight)), self._h)
 
     def fnet(self, lr_t, lr_tm1):
         B = int(np.shape(lr_t)[0])

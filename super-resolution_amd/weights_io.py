@@ -4,7 +4,9 @@ The reference stores Keras 2.2.4 ``save_weights`` HDF5 files (``demo.h5``, check
 layout: one group per top-level layer, only ``FNet`` (28 datasets) and
 ``SRNet`` (48 datasets) carry weights, dataset names ``<group>/conv2d_<n>/kernel:0`` etc., and
 Keras matches them to layers BY ORDER, not by name.  This module keeps exactly that contract on
-an ordered ``[(keras_name, float32 array)]`` list and supports two containers:
+an ordered ``[(keras_name, float32 array)]`` list (names carry the group, ``FNet/conv2d_1/kernel:0``; inside
+the file Keras stores ``weight_names`` WITHOUT it -- the variable name ``conv2d_1/kernel:0`` -- so the dataset
+sits at ``FNet/conv2d_1/kernel:0``; the writer does the same, the reader accepts both) and supports two containers:
 
   * ``.h5`` / ``.hdf5``  the Keras layout, read/written with h5py when it is importable, else with the
                 bundled ``h5lite`` (the subset of HDF5 that h5py's default format uses for such files;
@@ -53,7 +55,14 @@ def read_tensors(path):
     raise ValueError(f"{path}: unsupported weight file extension {ext!r} (use .h5 or .npz)")
 
 
-def write_tensors(path, tensors):
+def _local(name):
+    """Name of a weight inside its group, as Keras writes it: 'FNet/conv2d_1/kernel:0' -> 'conv2d_1/kernel:0'."""
+    return name.split("/", 1)[1] if "/" in name else name
+
+
+def write_tensors(path, tensors, weightless_layers=()):
+    """weightless_layers: names of extra top-level layers without weights (Keras lists every layer of the model in
+    ``layer_names`` -- the inputs, Upscaling_0, Warp_1 ... -- each with an empty group)."""
     tensors = [(n, np.ascontiguousarray(a, np.float32)) for n, a in tensors]
     ext = os.path.splitext(path)[1].lower()
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
@@ -64,7 +73,7 @@ def write_tensors(path, tensors):
             np.savez(fh, **arrays)
         return
     if ext in (".h5", ".hdf5"):
-        groups = []
+        groups = [str(g) for g in weightless_layers]
         for n, _ in tensors:
             if _group_of(n) not in groups:
                 groups.append(_group_of(n))
@@ -75,13 +84,13 @@ def write_tensors(path, tensors):
             root = {"attrs": {"layer_names": np.array([g.encode() for g in groups]), "backend": np.bytes_(b"tensorflow"),
                               "keras_version": np.bytes_(b"2.2.4")}, "children": {}}
             for g in groups:
-                names = [n for n, _ in tensors if _group_of(n) == g]
-                node = {"attrs": {"weight_names": np.array([n.encode() for n in names])}, "children": {}}
+                names = [_local(n) for n, _ in tensors if _group_of(n) == g]
+                node = {"attrs": {"weight_names": np.array([n.encode() for n in names])} if names else {}, "children": {}}
                 for n, a in tensors:
                     if _group_of(n) != g:
                         continue
-                    cur = node                            # dataset path = the weight name, as Keras writes it
-                    parts = n.split("/")
+                    cur = node                            # dataset path inside the group = the weight name, as Keras writes it
+                    parts = _local(n).split("/")
                     for part in parts[:-1]:
                         cur = cur["children"].setdefault(part, {"attrs": {}, "children": {}})
                     cur["children"][parts[-1]] = a
@@ -94,11 +103,11 @@ def write_tensors(path, tensors):
             f.attrs["keras_version"] = b"2.2.4"
             for g in groups:
                 lg = f.create_group(g)
-                names = [n for n, _ in tensors if _group_of(n) == g]
+                names = [_local(n) for n, _ in tensors if _group_of(n) == g]
                 lg.attrs["weight_names"] = [n.encode() for n in names]
                 for n, a in tensors:
                     if _group_of(n) == g:
-                        lg.create_dataset(n, data=a)
+                        lg.create_dataset(_local(n), data=a)
         return
     raise ValueError(f"{path}: unsupported weight file extension {ext!r} (use .h5 or .npz)")
 

@@ -111,8 +111,11 @@ def test_h5_weight_files_without_h5py(tmp_path, weights7):
     f = h5lite.File(path)
     assert [n.decode() for n in f.attrs["layer_names"]] == ["FNet", "SRNet"]
     assert len(f["FNet"].attrs["weight_names"]) == 28 and len(f["SRNet"].attrs["weight_names"]) == 48
-    k = f["SRNet/SRNet/conv2d_transpose_1/kernel:0"]
+    # Keras 2.2.4 layout: weight_names are the variable names (no group prefix), the dataset sits under its group
+    assert f["SRNet"].attrs["weight_names"][0] == b"conv2d_15/kernel:0"
+    k = f["SRNet/conv2d_transpose_1/kernel:0"]
     assert k.shape == (3, 3, 64, 64) and k.dtype == np.float32
+    assert [n for n, _ in weights_io.read_tensors(path)] == list(weights7.keys())
     m2 = FrameRecurrentVideoSR((16, 16, 3), (64, 64, 3), str(tmp_path), {"cnn": {}, "data": {}})
     m2.build()
     m2.frvsr.load_weights(path)
@@ -120,6 +123,29 @@ def test_h5_weight_files_without_h5py(tmp_path, weights7):
         np.testing.assert_array_equal(a, b)
     # sub-model loads only its own group, by position
     m2.fnet.load_weights(path)
+    # a file as Keras writes it for the whole model: every layer listed, the weightless ones with empty groups
+    full = str(tmp_path / "full.h5")
+    weights_io.write_tensors(full, list(weights7.items()), weightless_layers=["input_1", "input_2", "Upscaling_0", "Warp_1"])
+    assert [n.decode() for n in h5lite.File(full).attrs["layer_names"]][:4] == ["input_1", "input_2", "Upscaling_0", "Warp_1"]
+    m3 = FrameRecurrentVideoSR((16, 16, 3), (64, 64, 3), str(tmp_path), {"cnn": {}, "data": {}})
+    m3.build()
+    m3.frvsr.load_weights(full)
+    for a, b in zip(m3.frvsr.get_weights(), weights7.values()):
+        np.testing.assert_array_equal(a, b)
+    # the older layout of this repo (weight_names carrying the group prefix) still loads
+    old = {"attrs": {"layer_names": np.array([b"FNet", b"SRNet"])}, "children": {}}
+    for g in ("FNet", "SRNet"):
+        names = [n for n in weights7 if n.startswith(g + "/")]
+        node = {"attrs": {"weight_names": np.array([n.encode() for n in names])}, "children": {}}
+        for n in names:
+            cur = node
+            parts = n.split("/")
+            for part in parts[:-1]:
+                cur = cur["children"].setdefault(part, {"attrs": {}, "children": {}})
+            cur["children"][parts[-1]] = weights7[n]
+        old["children"][g] = node
+    h5lite.write_file(str(tmp_path / "old.h5"), old)
+    assert [n for n, _ in weights_io.read_tensors(str(tmp_path / "old.h5"))] == list(weights7.keys())
     # a real libhdf5 file: superblock at offset 512, old-style group, version-2 layout message
     import scipy.io
     real = os.path.join(os.path.dirname(scipy.io.__file__), "matlab", "tests", "data", "testhdf5_7.4_GLNX86.mat")
@@ -338,3 +364,36 @@ def test_get_frames_and_compile_surface(tmp_path):
     assert m.optimizer.lr == 1e-4 and m.optimizer.epsilon == 1e-7
     with pytest.raises(NotImplementedError):                 # second target must be I_LR_t
         m.train_on_batch([np.zeros((1, 16, 16, 3))] * 2 + [np.zeros((1, 64, 64, 3))], [np.zeros((1, 64, 64, 3)), np.ones((1, 16, 16, 3))])
+
+
+def test_product_synth_data_is_the_oracles_generator():
+    """super-resolution_amd/synth.py (what bench.py and the demo configs feed the generator) and the oracle's own
+    generator are separate code on purpose (the product imports nothing from oracle/); they must stay bit-identical
+    so that bench.py, the parity tests and the CPU baseline see the same clips and weights."""
+    import synth
+    from oracle import ref_numpy as rn
+    np.testing.assert_array_equal(synth.synth_clip(4, 3, 20, 36), rn.synth_clip(4, 3, 20, 36))
+    np.testing.assert_array_equal(synth.synth_clip(1, 2, 16, 24, scale=4), rn.synth_clip(1, 2, 16, 24, scale=4))
+    a, b = synth.make_weights(7), rn.make_weights(7)
+    assert list(a) == list(b)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torch.distributed.run starts 2 ranks itself (--gpus was
+    ignored); --launch-check makes them rendezvous over gloo without a GPU.  A launcher-provided WORLD_SIZE that
+    disagrees with --gpus is an error, not a silent 1-GPU run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["world_size_env"] == 2
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--launch-check"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

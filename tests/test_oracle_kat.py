@@ -197,3 +197,51 @@ def test_rng_is_stable():
     assert u.min() >= 0 and u.max() < 1
     np.testing.assert_array_equal(u, rn.uniform01(7, 4))
     assert not np.array_equal(u, rn.uniform01(8, 4))
+
+
+# ---- definitional checks, on random tensors ----------------------------------------------
+@pytest.mark.parametrize("H,W,Ci,Co", [(5, 7, 3, 4), (4, 4, 2, 2), (1, 6, 1, 3)])
+def test_conv_transpose_is_the_gradient_of_the_stride2_same_conv(H, W, Ci, Co):
+    """A.5 says what Conv2DTranspose(3x3, stride 2, 'same') IS in TF: conv2d_backprop_input of a stride-2 SAME
+    conv over a 2H x 2W tensor, whose SAME padding at even size and stride 2 is 0 before / 1 after.  Autograd
+    of exactly that forward conv must reproduce both restatements (a shifted 'padding=1, output_padding=1'
+    variant would not)."""
+    rng = np.random.default_rng(H * 10 + W)
+    x = rng.standard_normal((2, H, W, Ci)).astype(np.float32)            # the transposed conv's input = dY of the conv
+    w = rng.standard_normal((3, 3, Co, Ci)).astype(np.float32)           # Keras layout (kh, kw, filters, input_dim)
+    b = rng.standard_normal(Co).astype(np.float32)
+    # forward conv: u (2H, 2W, Co channels) -> (H, W, Ci), kernel HWIO (3, 3, Co, Ci) = the same array
+    u = torch.zeros(2, Co, 2 * H, 2 * W, dtype=torch.float64, requires_grad=True)
+    wf = torch.tensor(w, dtype=torch.float64).permute(3, 2, 0, 1)        # (out = Ci, in = Co, kh, kw)
+    y = torch.nn.functional.conv2d(torch.nn.functional.pad(u, (0, 1, 0, 1)), wf, stride=2)
+    assert y.shape == (2, Ci, H, W)
+    (g,) = torch.autograd.grad(y, u, torch.tensor(x, dtype=torch.float64).permute(0, 3, 1, 2))
+    want = g.permute(0, 2, 3, 1).numpy() + b
+    got_np = rn.conv_transpose3x3_s2_same(x, w, b)
+    got_t = rt.to_nhwc(rt.conv_transpose3x3_s2_same(rt.to_nchw(x), torch.tensor(w).permute(3, 2, 0, 1).contiguous(),
+                                                    torch.tensor(b)))
+    assert got_np.shape == (2, 2 * H, 2 * W, Co)
+    np.testing.assert_allclose(got_np, want, atol=2e-5)
+    np.testing.assert_allclose(got_t, want, atol=2e-5)
+
+
+@pytest.mark.parametrize("H,W", [(5, 7), (4, 6), (1, 3), (23, 40)])
+def test_maxpool_same_is_minus_inf_padding_bottom_right(H, W):
+    """A.2: SAME pooling at stride 2 pads only after the data (bottom / right) and the pad never wins."""
+    rng = np.random.default_rng(H + W)
+    x = -np.abs(rng.standard_normal((2, H, W, 3))).astype(np.float32) - 1.0     # all negative: a zero pad would win
+    xp = torch.nn.functional.pad(rt.to_nchw(x), (0, W % 2, 0, H % 2), value=float("-inf"))
+    want = rt.to_nhwc(torch.nn.functional.max_pool2d(xp, 2))
+    np.testing.assert_array_equal(rn.maxpool2_same(x), want)
+    np.testing.assert_array_equal(rt.to_nhwc(rt.maxpool2_same(rt.to_nchw(x))), want)
+
+
+def test_conv_same_is_zero_padding_one_cross_correlation():
+    """A.1 against torch's own conv2d(padding=1) on random data (no kernel flip, HWIO -> OIHW)."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 6, 5, 4)).astype(np.float32)
+    w = rng.standard_normal((3, 3, 4, 3)).astype(np.float32)
+    b = rng.standard_normal(3).astype(np.float32)
+    want = rt.to_nhwc(torch.nn.functional.conv2d(rt.to_nchw(x, torch.float64), torch.tensor(w, dtype=torch.float64).permute(3, 2, 0, 1),
+                                                 torch.tensor(b, dtype=torch.float64), padding=1))
+    np.testing.assert_allclose(rn.conv3x3_same(x, w, b), want, atol=2e-5)
