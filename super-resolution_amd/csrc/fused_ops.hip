@@ -500,16 +500,17 @@ hipError_t launch_crop_copy(const float* in, float* out, int B, int rows, int co
     return hipGetLastError();
 }
 
-// 4 floats -> 4 bytes per thread; row_elems (= 4w * 3) is a multiple of 4
-__global__ void denorm_u8_kernel(const float* __restrict__ est, unsigned char* __restrict__ out, int B, int HH, int row4, int rows) {
-    const long total = (long)B * rows * row4;
+// 4 floats -> 4 bytes per thread; both row lengths (4w * 3 elements, padded and cropped) are multiples of 4
+__global__ void denorm_u8_kernel(const float* __restrict__ est, unsigned char* __restrict__ out, int B, int HH, int row4_in,
+                                 int rows, int row4_out) {
+    const long total = (long)B * rows * row4_out;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int e = idx % row4;
-    long q = idx / row4;
+    const int e = idx % row4_out;
+    long q = idx / row4_out;
     const int y = q % rows;
     const int b = q / rows;
-    const float4 v = reinterpret_cast<const float4*>(est)[((size_t)b * HH + y) * row4 + e];
+    const float4 v = reinterpret_cast<const float4*>(est)[((size_t)b * HH + y) * row4_in + e];
     // numpy's float32 -> uint8 cast truncates toward zero and wraps modulo 256
     uchar4 o;
     o.x = (unsigned char)(int)(v.x * 255.0f);
@@ -519,10 +520,12 @@ __global__ void denorm_u8_kernel(const float* __restrict__ est, unsigned char* _
     reinterpret_cast<uchar4*>(out)[idx] = o;
 }
 
-hipError_t launch_denorm_u8(const float* est, unsigned char* out, int B, int HH, int row_elems, int rows, hipStream_t s) {
-    if (row_elems % 4) return hipErrorInvalidValue;
-    const long total = (long)B * rows * (row_elems / 4);
-    hipLaunchKernelGGL(denorm_u8_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, est, out, B, HH, row_elems / 4, rows);
+hipError_t launch_denorm_u8(const float* est, unsigned char* out, int B, int HH, int row_elems, int rows, int row_elems_out,
+                            hipStream_t s) {
+    if (row_elems % 4 || row_elems_out % 4 || row_elems_out > row_elems) return hipErrorInvalidValue;
+    const long total = (long)B * rows * (row_elems_out / 4);
+    hipLaunchKernelGGL(denorm_u8_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, est, out, B, HH, row_elems / 4, rows,
+                       row_elems_out / 4);
     return hipGetLastError();
 }
 

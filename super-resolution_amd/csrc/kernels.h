@@ -86,8 +86,10 @@ hipError_t launch_blur_cubic_down4(const float* hr, float* lr, int N, int H, int
 // dense [B,rows,cols,ch] <-> zero-padded [B,rows_p,cols_p,ch] (pad mode of sr_create_padded: bottom / right padding)
 hipError_t launch_pad_copy(const float* in, float* out, int B, int rows, int cols, int ch, int rows_p, int cols_p, hipStream_t s);
 hipError_t launch_crop_copy(const float* in, float* out, int B, int rows, int cols, int ch, int rows_p, int cols_p, hipStream_t s);
-// reference utils.py:61-63 denormalize: (x * 255).astype(uint8) (truncation), rows [0, rows) of each [HH, row_elems] image
-hipError_t launch_denorm_u8(const float* est, unsigned char* out, int B, int HH, int row_elems, int rows, hipStream_t s);
+// reference utils.py:61-63 denormalize: (x * 255).astype(uint8) (truncation); rows [0, rows) and the first row_elems_out
+// elements of every row of each [HH, row_elems] image, dense output
+hipError_t launch_denorm_u8(const float* est, unsigned char* out, int B, int HH, int row_elems, int rows, int row_elems_out,
+                            hipStream_t s);
 
 // generic fp32 single ops for the per-op C-ABI entry points
 hipError_t launch_pad_channels(const float* in, void* out, int out_bf16, long npix, int C, int Cp, hipStream_t s);

@@ -917,15 +917,11 @@ int sr_clip_push_u8(sr_ctx* c, const float* lr_t, int lr_on_device, uint8_t* est
     const float* est = c->d_est[c->cur];   // the estimate this push produced (state already swapped)
     hipStream_t st = c->stream;
     if (c->u8_pushes >= 2) HIPCHK(c, hipStreamWaitEvent(st, c->ev_u8_done[slot], 0));   // frame n-2 has left this slot
-    LAUNCHCHK(c, "denorm_u8", launch_denorm_u8(est, c->d_u8[slot], B, 4 * c->h, 4 * c->w * 3, 4 * c->h_in, st));
+    LAUNCHCHK(c, "denorm_u8", launch_denorm_u8(est, c->d_u8[slot], B, 4 * c->h, 4 * c->w * 3, 4 * c->h_in, 4 * c->w_in * 3, st));
     HIPCHK(c, hipEventRecord(c->ev_u8_ready[slot], st));
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_u8_ready[slot], 0));
-    // rows are cropped by the kernel; columns only when the width was padded (then row by row)
-    const size_t row = (size_t)4 * c->w_in * 3, rows = (size_t)B * 4 * c->h_in;
-    if (c->w == c->w_in)
-        HIPCHK(c, hipMemcpyAsync(est_u8_host, c->d_u8[slot], rows * row, hipMemcpyDeviceToHost, c->copy_stream));
-    else
-        HIPCHK(c, hipMemcpy2DAsync(est_u8_host, row, c->d_u8[slot], (size_t)4 * c->w * 3, row, rows, hipMemcpyDeviceToHost, c->copy_stream));
+    // the kernel cropped rows and columns: one dense copy
+    HIPCHK(c, hipMemcpyAsync(est_u8_host, c->d_u8[slot], (size_t)B * 16 * c->h_in * c->w_in * 3, hipMemcpyDeviceToHost, c->copy_stream));
     HIPCHK(c, hipEventRecord(c->ev_u8_done[slot], c->copy_stream));
     ++c->u8_pushes;
     return SR_OK;
