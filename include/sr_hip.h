@@ -236,6 +236,22 @@ int sr_op_resize_bilinear_bwd(int device, int B, int H, int W, int C, int s, con
 int sr_op_warp_bwd_flow(int device, int B, int H, int W, int C, const float* img, const float* flow,
                         const float* g, float* gflow);
 
+/* The ONE entry point that allocates nothing.  It has no counterpart in the reference; it exists for callers
+ * that cannot call hipMalloc: code under HIP graph capture, tight training loops, harnesses that forbid
+ * allocation.  It is sr_op_conv3x3_bwd's kernel / bias gradient (dw (3,3,Cin,Cout) HWIO, db (Cout,), db may be
+ * NULL) of Conv2D 3x3 'same' from x (B,H,W,Cin) and dy (B,H,W,Cout), but on DEVICE pointers (dense NHWC
+ * float32), asynchronous on `hip_stream` (a hipStream_t, NULL = the default stream), and with the per-slice
+ * partial sums of its kernels in a static device array of SR_NOALLOC_SCRATCH_BYTES that every GPU the library
+ * runs on holds until the process ends, instead of a hipMalloc'ed workspace.  Shapes whose partials do not fit
+ * are rejected with SR_ERR_ARG: the partials take 37 KB x ceil(Cin/32) x ceil(Cout/32) x slice groups, and the
+ * slice plan keeps that near 19 MB for any image size while Cin x Cout <= 2048 x 1024 or so (every layer of
+ * this network fits at any batch; 2048 -> 2048 channels would need 152 MB and is refused).  Every call on a GPU shares that GPU's array: calls that overlap on one
+ * GPU (different streams or threads) race; calls on one stream are safe back to back.  It calls no hipMalloc /
+ * hipFree; the first call on a device only looks up the array's address (hipGetSymbolAddress). */
+#define SR_NOALLOC_SCRATCH_BYTES (32 * 1024 * 1024)
+int sr_op_conv3x3_wgrad_noalloc(int device, int dtype, int B, int H, int W, int Cin, int Cout, const float* d_x,
+                                const float* d_dy, float* d_dw, float* d_db, void* hip_stream);
+
 /* Measurement utility (no reference counterpart): times `iters` back-to-back launches
  * of one 3x3 conv (or stride-2 transposed conv) layer on device-resident random data
  * with HIP events; used by tools/conv_bench.py to iterate on the MFMA kernels. */

@@ -70,6 +70,7 @@ SIGNATURES = {
     "sr_op_maxpool2_bwd": (C.c_int, [C.c_int] * 5 + [_vp] * 3),
     "sr_op_resize_bilinear_bwd": (C.c_int, [C.c_int] * 6 + [_vp] * 2),
     "sr_op_warp_bwd_flow": (C.c_int, [C.c_int] * 5 + [_vp] * 4),
+    "sr_op_conv3x3_wgrad_noalloc": (C.c_int, [C.c_int] * 7 + [_vp] * 5),
     "sr_bench_conv": (C.c_int, [C.c_int] * 10 + [C.POINTER(C.c_float)]),
 }
 
@@ -464,6 +465,12 @@ def warp_bwd_flow(img, flow, g, device=0):
     out = np.empty((B, H, W, 2), np.float32)
     _check(lib().sr_op_warp_bwd_flow(device, B, H, W, Cc, _ptr(img), _ptr(flow), _ptr(g), _ptr(out)))
     return out
+
+
+def conv3x3_wgrad_noalloc(B, H, W, Cin, Cout, d_x, d_dy, d_dw, d_db=None, dtype="fp32", stream=None, device=0):
+    """Device pointers (ints); asynchronous on `stream`.  Allocates nothing (include/sr_hip.h)."""
+    _check(lib().sr_op_conv3x3_wgrad_noalloc(device, DTYPES[dtype], B, H, W, Cin, Cout, _vp(d_x), _vp(d_dy), _vp(d_dw),
+                                             _vp(d_db) if d_db else None, _vp(stream) if stream else None))
 
 
 def bench_conv(B, H, W, Cin, Cout, dtype="bf16x3", transposed=False, residual=False, iters=20, device=0):
