@@ -138,14 +138,21 @@ __device__ __forceinline__ void stage_load(u32x4 (&regs)[G::ITER], const unsigne
     }
 }
 
+// split: the vectors are units of a split-planar tensor (conv_trunk.hip) -- 8 bf16 hi or lo parts, already in the order
+// the packed weights (pack_entries kperm) expect -- and go to the hi / lo tile as they are
 template <class G, int PREC>
-__device__ __forceinline__ void stage_store(const u32x4 (&regs)[G::ITER], unsigned char* smem, int tid) {
+__device__ __forceinline__ void stage_store(const u32x4 (&regs)[G::ITER], unsigned char* smem, int tid, int split = 0) {
 #pragma unroll
     for (int it = 0; it < G::ITER; ++it) {
         const int v = tid + it * 256;
         if (v < G::NV) {
             const int p = v / G::VPP, part = v % G::VPP;
             if constexpr (PREC == P_BF16X3) {
+                if (split) {   // part = 4 * plane + unit; unit = 2 h + (0: hi, 1: lo); k-step = plane
+                    const int u = part & 3;
+                    *reinterpret_cast<u32x4*>(smem + (u & 1) * G::TILE_BYTES + p * G::PS + 32 * (part >> 2) + 16 * (u >> 1)) = regs[it];
+                    continue;
+                }
                 const f32x4 f = __builtin_bit_cast(f32x4, regs[it]);
                 bf16x4 hi, lo;
 #pragma unroll
@@ -1047,7 +1054,7 @@ __global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) 
         u32x4 regs[G::ITER];
         stage_load<G, PREC>(regs, inb, 0, a.cin_p, y0, x0, H, W, tid, a.in_planar);
         load_tap(0);
-        stage_store<G, PREC>(regs, smem, tid);
+        stage_store<G, PREC>(regs, smem, tid, a.in_split);
     }
     store_tap(0);
     load_tap(1);

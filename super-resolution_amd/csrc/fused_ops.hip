@@ -171,7 +171,9 @@ hipError_t launch_resize2x(const void* in, void* out, int act_bf16, int B, int H
 // One workgroup = 64 consecutive LR pixels x 4 sub-rows (dy).  Thread (lp, dy) upsamples the
 // flow for its 4 HR pixels, gathers/warps 4 x 3 values of the previous estimate and drops them
 // at channels 3 + dy*12 .. of its pixel's 64-channel row in LDS; rows go out as 16-B vectors.
-template <typename T, bool WRITE_HR>
+// SPLIT: the 64-channel rows leave as split-planar records (conv_trunk.hip: [B][4 planes][H][W][64 B], units of 8 bf16
+// hi | lo parts in the channel order kernels.h split_perm) instead of NHWC rows.
+template <typename T, bool WRITE_HR, bool SPLIT = false>
 __global__ __launch_bounds__(256) void pre_srnet_kernel(const float* __restrict__ flow, const float* __restrict__ est,
                                                         const float* __restrict__ lr, T* __restrict__ out,
                                                         float* __restrict__ hr_out, int B, int H, int W) {
@@ -228,6 +230,29 @@ __global__ __launch_bounds__(256) void pre_srnet_kernel(const float* __restrict_
         }
     }
     __syncthreads();
+    if constexpr (SPLIT) {
+        // thread v -> (plane, row, unit): per plane the 64 rows x 4 units are 4 KiB of consecutive global bytes
+        const size_t hw = (size_t)H * W;
+        for (int v = threadIdx.x; v < 1024; v += 256) {
+            const int plane = v >> 8, row = (v >> 2) & 63, u = v & 3;
+            const long pp = (long)blockIdx.x * 64 + row;
+            if (pp < npix) {
+                const int hh = u >> 1;
+                typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+                bf16x8v o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = rows[row][16 * plane + split_perm(hh, e)];
+                    const __bf16 hi = (__bf16)f;
+                    o[e] = (u & 1) ? (__bf16)(f - (float)hi) : hi;
+                }
+                const size_t b = (size_t)(pp / (long)hw), pix = (size_t)pp - b * hw;
+                unsigned char* dst = reinterpret_cast<unsigned char*>(out) + ((b * 4 + plane) * hw + pix) * 64 + u * 16;
+                *reinterpret_cast<bf16x8v*>(dst) = o;
+            }
+        }
+        return;
+    }
     // 64 rows x 64 channels -> global, 16 B per thread per pass, fully coalesced
     constexpr int N = Vec<T>::N;
     constexpr int VPR = 64 / N;               // vectors per row
@@ -247,7 +272,10 @@ hipError_t launch_pre_srnet(const float* flow, const float* est_prev, const floa
                             float* hr_warp_out, int act_bf16, int B, int H, int W, hipStream_t s) {
     const long npix = (long)B * H * W;
     const dim3 grid(blocks_for(npix, 64)), block(256);
-    if (act_bf16) {
+    if (act_bf16 == 2) {
+        if (hr_warp_out) hipLaunchKernelGGL((pre_srnet_kernel<float, true, true>), grid, block, 0, s, flow, est_prev, lr_t, (float*)out, hr_warp_out, B, H, W);
+        else hipLaunchKernelGGL((pre_srnet_kernel<float, false, true>), grid, block, 0, s, flow, est_prev, lr_t, (float*)out, hr_warp_out, B, H, W);
+    } else if (act_bf16) {
         if (hr_warp_out) hipLaunchKernelGGL((pre_srnet_kernel<__bf16, true>), grid, block, 0, s, flow, est_prev, lr_t, (__bf16*)out, hr_warp_out, B, H, W);
         else hipLaunchKernelGGL((pre_srnet_kernel<__bf16, false>), grid, block, 0, s, flow, est_prev, lr_t, (__bf16*)out, hr_warp_out, B, H, W);
     } else {

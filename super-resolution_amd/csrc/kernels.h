@@ -35,6 +35,8 @@ struct ConvArgs {
     // one conv chunk (16 fp32 / 32 bf16 channels), so a chunk's halo row is contiguous full 128-B
     // lines instead of a 64-byte half of every pixel's lines.  Image stride is the same either way.
     int in_planar;         // input is planar (needs 64-byte chunks: steps == prec_maxsteps)
+    int in_split;          // transposed conv, bf16x3: the planar input is split-planar (conv_trunk.hip): units of 8 bf16 (hi | lo)
+                           // in permuted channel order go to the hi / lo LDS tiles as they are; weights packed with kperm
     int out_planar;        // output and residual are planar (cout_store a multiple of 64 bytes)
     // transposed conv only: packed 64 x 27 tap-projection weights of the following <= 3-channel conv
     // (conv_mfma.hip epilogue_proj); out is then the fp32 P tensor [B,2H,2W,32]; nullptr = plain epilogue
@@ -59,6 +61,25 @@ __host__ __device__ constexpr int prec_maxsteps(int prec, int mode) {
 // taps-in-N kernel for <= 3 output channels (conv_tapsn.hip): channels per chunk = one 128-B line per pixel
 __host__ __device__ constexpr int tapsn_chunk(int prec) { return prec == P_BF16 ? 64 : 32; }
 
+// SRNet trunk conv on split-planar activations (conv_trunk.hip): 64 -> 64 channels, bf16x3 arithmetic.
+// Tensors are [B][4 planes][H][W][64 B]; see conv_trunk.hip for the record layout.
+struct TrunkArgs {
+    const unsigned char* in;
+    unsigned char* out;
+    const unsigned char* res;     // residual added after the activation (may be `out`), or nullptr
+    const unsigned char* wpack;   // [2 halves][4 chunks][9 taps][hi, lo][64 lanes] x 16 B (sr_api.hip trunk_entries)
+    const float* bias;            // [64]
+    unsigned zero_off;            // byte offset from `in` of 64 zero bytes (behind the tensor): the source of halo pixels outside the image
+    int B, H, W;
+    int relu;                     // ReLU after the bias (before the residual)
+    int tiles_x, tiles_y;         // set by the launcher
+    int dbg;                      // ablation switches for the micro-benchmark (0 in production): 1 no tile DMA, 2 no MFMA loop, 4 no epilogue memory traffic
+};
+hipError_t launch_trunk_conv(TrunkArgs a, hipStream_t s);
+size_t trunk_weight_bytes();
+// channel of k index (half h, element e) inside a 16-channel plane of the split-planar layout
+__host__ __device__ constexpr int split_perm(int h, int e) { return e < 4 ? 4 * h + e : 8 + 4 * h + (e - 4); }
+
 // host-side launchers (conv_mfma.hip, conv_tapsn.hip)
 hipError_t launch_conv(int prec, int mode, int nt, int steps, const ConvArgs& a, int ncb, hipStream_t s);
 hipError_t launch_conv_tapsn(int prec, int nchunk, const ConvArgs& a, hipStream_t s);
@@ -71,6 +92,7 @@ hipError_t launch_fnet_input(const float* lr_t, const float* lr_tm1, void* out, 
                              int B, int H, int W, hipStream_t s);
 hipError_t launch_maxpool2(const void* in, void* out, int act_bf16, int B, int H, int W, int C, hipStream_t s);
 hipError_t launch_resize2x(const void* in, void* out, int act_bf16, int B, int H, int W, int C, hipStream_t s);
+// act_bf16 = 2: the output is split-planar (conv_trunk.hip) instead of NHWC
 hipError_t launch_pre_srnet(const float* flow, const float* est_prev, const float* lr_t, void* out,
                             float* hr_warp_out, int act_bf16, int B, int H, int W, hipStream_t s);
 hipError_t launch_srnet_input(const float* lr_t, const float* s_s, void* out, int act_bf16,

@@ -85,7 +85,7 @@ void plan_layer(ConvLayer& L, int prec, int mode, int cin, int cout) {
 // The non-zero elements of L's packed weight buffer (see PackEnt).  kind PK_DGRAD: L is the data-gradient
 // conv of a forward Conv2D (cin, cout swapped, taps mirrored) and src indexes the FORWARD layer's kernel:
 //   dX[y,x,ci] = sum dY[y+1-ky, x+1-kx, co] W[ky,kx,ci,co]  =  conv3x3(dY, W'),  W'[ky,kx,co,ci] = W[2-ky,2-kx,ci,co]
-std::vector<PackEnt> pack_entries(const ConvLayer& L, int prec, int kind) {
+std::vector<PackEnt> pack_entries(const ConvLayer& L, int prec, int kind, bool kperm) {
     const int ks = prec_ks(prec), half = ks / 2;
     const int bv = prec == P_BF16X3 ? 2 : 1;
     const int ckc = L.steps * ks;
@@ -129,13 +129,33 @@ std::vector<PackEnt> pack_entries(const ConvLayer& L, int prec, int kind) {
                                 const int co = (cb * L.nt + n) * 32 + j;
                                 const size_t vbase = (size_t)cb * L.wstride_cb + (gstep * L.nt + n) * bv * 64;
                                 for (int e = 0; e < half; ++e) {
-                                    const int ci = c * ckc + s * ks + half * hh + e;
+                                    // kperm: the input is split-planar, k index (hh, e) of a 16-channel step is channel split_perm(hh, e)
+                                    const int ci = c * ckc + s * ks + (kperm ? split_perm(hh, e) : half * hh + e);
                                     const int32_t src = W(tap, ci, co);
                                     if (src >= 0) out.push_back({src, (uint32_t)((vbase + lane) * half + e)});
                                 }
                             }
                     }
     }
+    return out;
+}
+
+// conv_trunk.hip: [half of cout][16-channel plane of cin][tap][hi, lo][lane (j, hh)] x 8 bf16, lane (j, hh) element e =
+// kernel[tap][16 plane + split_perm(hh, e)][32 half + j]; hi / lo blocks are 512 elements apart like everywhere else
+std::vector<PackEnt> trunk_entries(int cin, int cout) {
+    std::vector<PackEnt> out;
+    for (int hf = 0; hf < 2; ++hf)
+        for (int c = 0; c < 4; ++c)
+            for (int t = 0; t < 9; ++t)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int j = lane & 31, hh = lane >> 5, co = 32 * hf + j;
+                    const size_t vbase = ((size_t)((hf * 4 + c) * 9 + t) * 2) * 64;
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = 16 * c + split_perm(hh, e);
+                        if (ci < cin && co < cout)
+                            out.push_back({(int32_t)(((size_t)t * cin + ci) * cout + co), (uint32_t)((vbase + lane) * 8 + e)});
+                    }
+                }
     return out;
 }
 
@@ -176,8 +196,17 @@ int upload_layer(sr_ctx* c, ConvLayer& L, int prec, const float* w, const float*
     return SR_OK;
 }
 
+int upload_alt(sr_ctx* c, ConvLayer& L, size_t bytes, const float* w) {
+    std::vector<uint8_t> packed = pack_apply(L.ents2, bytes, P_BF16X3, w);
+    if (L.d_w2) (void)hipFree(L.d_w2);
+    L.d_w2 = nullptr;
+    HIPCHK(c, hipMalloc(&L.d_w2, packed.size()));
+    HIPCHK(c, hipMemcpy(L.d_w2, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    return SR_OK;
+}
+
 void free_layer(ConvLayer& L) {
-    void* ps[] = {L.d_w, L.d_bias, L.d_proj, L.d_ents, L.d_proj_ents};
+    void* ps[] = {L.d_w, L.d_bias, L.d_proj, L.d_ents, L.d_proj_ents, L.d_w2, L.d_ents2};
     for (void* p : ps)
         if (p) (void)hipFree(p);
     L.d_w = nullptr;
@@ -185,6 +214,8 @@ void free_layer(ConvLayer& L) {
     L.d_proj = nullptr;
     L.d_ents = nullptr;
     L.d_proj_ents = nullptr;
+    L.d_w2 = nullptr;
+    L.d_ents2 = nullptr;
 }
 
 // Tap-projection weights for conv_mfma.hip epilogue_proj: the following conv's kernel w[3,3,64,cout<=3]
@@ -280,6 +311,12 @@ int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, con
     a.out_planar = io.out_planar;
     a.proj_w = io.proj_w;
     a.res_mask = io.res_mask;
+    a.in_split = io.in_split;
+    if (io.in_split) {
+        if (L.mode != M_CONVT || prec != P_BF16X3 || !io.in_planar || !L.d_w2 || L.nchunk != 1 || L.steps != 4)
+            return fail(c, SR_ERR_ARG, "%s: a split-planar input needs the bf16x3 64-channel transposed conv with its second packing", name);
+        a.wpack = L.d_w2;
+    }
     if (io.res_mask && (L.tapsn || L.mode != M_CONV || prec == P_BF16 || !io.res || io.out_planar || io.proj_w ||
                         (io.act != A_RELU && io.act != A_LRELU) || io.cout_store % 8 || io.out_cs % 8 || io.res_cs % 8))
         return fail(c, SR_ERR_ARG, "%s: masked data-gradient needs an fp32/bf16x3 3x3 conv with vector-aligned strides", name);
@@ -319,12 +356,20 @@ int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, con
 }
 
 
+// every buffer is followed by 256 zero bytes: conv_trunk.hip reads the halo pixels that lie outside the image from there
 int alloc_buf(sr_ctx* c, const char* name, size_t bytes) {
     void* p = nullptr;
-    HIPCHK(c, hipMalloc(&p, bytes));
+    HIPCHK(c, hipMalloc(&p, bytes + 256));
+    HIPCHK(c, hipMemset((unsigned char*)p + bytes, 0, 256));
     c->buf[name] = p;
     c->buf_img_bytes[name] = bytes / (size_t)c->max_batch;
     return SR_OK;
+}
+
+// split-planar trunk (conv_trunk.hip) for this step?
+bool use_split(const sr_ctx* c, int B) {
+    if (c->prec != P_BF16X3 || !c->split_trunk || !c->srnet[0].d_w2) return false;
+    return c->split_trunk >= 2 || (size_t)B * c->h * c->w > 65536;
 }
 
 // stream and activation buffers of the lane being enqueued (whole batch on `stream` outside a fork)
@@ -417,7 +462,7 @@ int run_fnet(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, float
 // that its two ping-pong activation tensors stay resident in the 256 MiB Infinity Cache between
 // layers instead of streaming through HBM 41 times per frame (SR_TRUNK_SUB=n overrides the automatic
 // choice; a value >= the batch disables the split).
-int run_srnet(sr_ctx* c, int B, float* d_out) {
+int run_srnet(sr_ctx* c, int B, float* d_out, bool split) {
     const int P = c->prec, af = c->prec == P_BF16 ? 0 : 1;
     hipStream_t st = lane_st(c);
     const int H = c->h, W = c->w;
@@ -429,6 +474,7 @@ int run_srnet(sr_ctx* c, int B, float* d_out) {
         const size_t img = (size_t)H * W * 64 * es;
         const int lanes = c->lane_stream ? c->dual + 1 : 1;
         sub = (int)std::max<size_t>(1, ((size_t)128 << 20) / ((size_t)lanes * 2 * img));
+        if (split) sub = B;   // persistent one-workgroup-per-CU launches want many tiles each
     }
     sub = std::min(sub, B);
     for (int b0 = 0; b0 < B; b0 += sub) {
@@ -437,6 +483,27 @@ int run_srnet(sr_ctx* c, int B, float* d_out) {
         unsigned char* s_in = (unsigned char*)lane_buf(c, "s_in") + off;
         unsigned char* sx = (unsigned char*)lane_buf(c, "sx") + off;
         unsigned char* sy = (unsigned char*)lane_buf(c, "sy") + off;
+        if (split) {
+            // all three tensors are split-planar and of one size; the zero tail sits behind image max_batch - 1
+            const size_t img = (size_t)H * W * 256;
+            const size_t tail = (size_t)(c->max_batch - c->lane_b0 - b0) * img;
+            auto trunk = [&](const ConvLayer& L, const unsigned char* in, unsigned char* out, const unsigned char* res, int relu,
+                             const char* name) -> int {
+                TrunkArgs ta = {in, out, res, (const unsigned char*)L.d_w2, L.d_bias, (unsigned)tail, nb, H, W, relu, 0, 0, 0};
+                const double px = (double)nb * H * W;
+                ProfScope ps(c, name, px * 9.0 * L.cin * L.cout * 2.0, px * 256.0 * (res ? 3 : 2) + (double)trunk_weight_bytes());
+                if (tail + 64 > 4294967295.0) return fail(c, SR_ERR_ARG, "%s: tensor too large for 32-bit offsets", name);
+                LAUNCHCHK(c, name, launch_trunk_conv(ta, st));
+                return SR_OK;
+            };
+            int rc = trunk(c->srnet[0], s_in, sx, nullptr, 1, "srnet.head");
+            if (rc) return rc;
+            for (int r = 0; r < 10; ++r) {
+                if ((rc = trunk(c->srnet[1 + 2 * r], sx, sy, nullptr, 1, "srnet.res"))) return rc;
+                if ((rc = trunk(c->srnet[2 + 2 * r], sy, sx, sx, 0, "srnet.res"))) return rc;   // x = x + conv(y), in place
+            }
+            continue;
+        }
         const int pl = c->planar_trunk;   // trunk activations in 64-byte planes (kernels.h)
         int rc = run_conv(c, P, st, c->srnet[0], nb, {s_in, H, W, sx, 64, 64, af, nullptr, 0, A_RELU, 0, pl}, "srnet.head");
         if (rc) return rc;
@@ -449,7 +516,9 @@ int run_srnet(sr_ctx* c, int B, float* d_out) {
         }
     }
     auto b = [&](const char* n) { return lane_buf(c, n); };
-    int rc = run_conv(c, P, st, c->srnet[21], B, {b("sx"), H, W, b("up1"), 64, 64, af, nullptr, 0, A_RELU, c->planar_trunk, 0}, "srnet.up1");
+    ConvIO up1 = {b("sx"), H, W, b("up1"), 64, 64, af, nullptr, 0, A_RELU, split ? 1 : c->planar_trunk, 0};
+    up1.in_split = split ? 1 : 0;
+    int rc = run_conv(c, P, st, c->srnet[21], B, up1, "srnet.up1");
     if (rc) return rc;
     if (c->srnet[22].d_proj) {
         // conv2d_transpose_2 + ReLU + the 64 x 27 tap projection of conv2d_36 in one kernel: "up2" holds
@@ -486,6 +555,7 @@ int run_step_lane(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, 
     const int H = c->h, W = c->w;
     hipStream_t st = lane_st(c);
     float* d_flow = c->d_flow + (size_t)c->lane_b0 * H * W * 2;
+    const bool split = c->step_split;   // decided per step (run_step), the same for every lane
     int rc = run_fnet(c, B, d_lr_t, d_lr_tm1, d_flow);
     if (rc) return rc;
     if (d_lr_warp) {
@@ -496,10 +566,10 @@ int run_step_lane(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, 
         // algorithmic bytes per LR pixel: read 2 flow + 48 prev-est + 3 LR (fp32), write 64 activations
         const double bytes = (double)B * H * W * (4.0 * (2 + 48 + 3) + 64.0 * (bf ? 2 : 4) + (d_hr_warp ? 192.0 : 0.0));
         ProfScope ps(c, "pre_srnet", 0, bytes);
-        LAUNCHCHK(c, "pre_srnet", launch_pre_srnet(d_flow, d_est_prev, d_lr_t, lane_buf(c, "s_in"), d_hr_warp, bf, B, H, W, st));
+        LAUNCHCHK(c, "pre_srnet", launch_pre_srnet(d_flow, d_est_prev, d_lr_t, lane_buf(c, "s_in"), d_hr_warp, split ? 2 : bf, B, H, W, st));
     }
     if (warp_only) return SR_OK;
-    rc = run_srnet(c, B, d_est_out);
+    rc = run_srnet(c, B, d_est_out, split);
     if (rc) return rc;
     if (c->model == SR_TECOGAN) {
         ProfScope ps(c, "teco_epilogue", 0, (double)B * H * W * (12.0 + 2 * 192.0));
@@ -515,6 +585,7 @@ int run_step(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, const
     // doubles the launches (measured 14.6 -> 12.9 ms per iteration with one lane)
     const bool tiny = (size_t)B * c->h * c->w <= 65536;
     const int lanes = tiny ? 1 : std::min(c->dual + 1, B);
+    c->step_split = use_split(c, B);
     if (lanes < 2 || c->prof_on)
         return run_step_lane(c, B, d_lr_t, d_lr_tm1, d_est_prev, d_est_out, d_lr_warp, d_hr_warp, warp_only);
     const size_t lr = (size_t)c->h * c->w * 3, hr = lr * 16;
@@ -628,6 +699,7 @@ static int create_common(sr_ctx** out, int device, int h_in, int w_in, int ch, i
     c->model = model;
     if (const char* e = getenv("SR_TRUNK_SUB")) c->trunk_sub = atoi(e);
     if (getenv("SR_NO_PLANAR")) c->planar_trunk = 0;
+    if (const char* e = getenv("SR_SPLIT_TRUNK")) c->split_trunk = atoi(e);
     int rc = SR_OK;
     auto bail = [&](int code) {
         g_err = c->err;
@@ -790,6 +862,15 @@ int sr_commit_weights(sr_ctx* c) {
         plan_layer(c->srnet[i], c->prec, mode, cin, cout);
         int rc = upload_layer(c, c->srnet[i], c->prec, c->tensors[28 + 2 * i].data.data(), c->tensors[28 + 2 * i + 1].data.data());
         if (rc) return rc;
+    }
+    if (c->prec == P_BF16X3 && c->split_trunk) {   // split-planar trunk: second packing of the 21 trunk convs and of conv2d_transpose_1
+        for (int i = 0; i <= 21; ++i) {
+            ConvLayer& L = c->srnet[i];
+            L.ents2 = i < 21 ? trunk_entries(L.cin, L.cout) : pack_entries(L, c->prec, PK_FWD, true);
+            const size_t bytes = i < 21 ? trunk_weight_bytes() : (size_t)L.ncb * L.wstride_cb * 16;
+            int rc = upload_alt(c, L, bytes, c->tensors[28 + 2 * i].data.data());
+            if (rc) return rc;
+        }
     }
     if (!getenv("SR_NO_FUSE_OUT")) {   // SRNet tail: conv2d_transpose_2 carries conv2d_36's tap projection
         int rc = upload_proj(c, c->srnet[22], c->prec, c->tensors[28 + 2 * 23].data.data(), 3);
@@ -963,7 +1044,7 @@ int sr_srnet(sr_ctx* c, int B, const float* lr_t, const float* s_s, float* out) 
     hipStream_t st = c->stream;
     if ((rc = put_in(c, c->d_lr_t, lr_t, false, B, 1, 3)) || (rc = put_in(c, c->d_ss, s_s, false, B, 1, 48))) return rc;
     LAUNCHCHK(c, "srnet.input", launch_srnet_input(c->d_lr_t, c->d_ss, c->buf["s_in"], c->prec == P_BF16, B, c->h, c->w, st));
-    rc = run_srnet(c, B, c->d_est[1]);
+    rc = run_srnet(c, B, c->d_est[1], false);   // srnet_input writes the NHWC trunk input
     if (rc) return rc;
     if ((rc = get_out(c, out, false, c->d_est[1], B, 4, 3))) return rc;
     HIPCHK(c, hipStreamSynchronize(st));
@@ -1153,6 +1234,33 @@ int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, in
     if ((rc = upload_layer(nullptr, L, dtype, w.data(), bias.data()))) return rc;
     DevBufs d;
     const size_t npix = (size_t)B * H * W, opix = mode == M_CONV ? npix : 4 * npix;
+    if (getenv("SR_BENCH_TRUNK") && dtype == SR_BF16X3 && !transposed && Cin == 64 && Cout == 64) {
+        // the split-planar trunk kernel (conv_trunk.hip) on random bf16 pairs; ablations via SR_CONV_DBG
+        L.ents2 = trunk_entries(64, 64);
+        if ((rc = upload_alt(nullptr, L, trunk_weight_bytes(), w.data()))) return rc;
+        const size_t bytes = npix * 256;
+        unsigned char* bufs[2] = {(unsigned char*)d.get(bytes + 256), (unsigned char*)d.get(bytes + 256)};
+        if (!bufs[0] || !bufs[1]) return fail(nullptr, SR_ERR_HIP, "hipMalloc failed");
+        std::vector<uint16_t> hb((bytes + 256) / 2);
+        for (size_t i = 0; i < bytes / 2; ++i) hb[i] = f2bf(rnd() * ((i / 8) & 1 ? 0.004f : 1.f));   // units alternate hi | lo
+        for (int k = 0; k < 2; ++k) HIPCHK(nullptr, hipMemcpy(bufs[k], hb.data(), bytes + 256, hipMemcpyHostToDevice));
+        TrunkArgs ta = {bufs[0], bufs[1], residual ? bufs[1] : nullptr, (const unsigned char*)L.d_w2, L.d_bias, (unsigned)bytes,
+                        B, H, W, 1, 0, 0, g_conv_dbg};
+        hipEvent_t e0, e1;
+        HIPCHK(nullptr, hipEventCreate(&e0));
+        HIPCHK(nullptr, hipEventCreate(&e1));
+        for (int i = 0; i < 3; ++i) LAUNCHCHK(nullptr, "trunk", launch_trunk_conv(ta, nullptr));
+        HIPCHK(nullptr, hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) LAUNCHCHK(nullptr, "trunk", launch_trunk_conv(ta, nullptr));
+        HIPCHK(nullptr, hipEventRecord(e1, nullptr));
+        HIPCHK(nullptr, hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(nullptr, hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *ms_per_launch = ms / iters;
+        return SR_OK;
+    }
     const size_t es = dtype == SR_BF16 ? 2 : 4;
     const bool out_f32 = dtype != SR_BF16 || L.tapsn;   // image / flow outputs are always fp32
     const int cout_p = L.tapsn ? Cout : round_up(Cout, 16);

@@ -39,6 +39,12 @@ struct ConvLayer {
     void* d_w = nullptr;
     float* d_bias = nullptr;
     void* d_proj = nullptr;   // transposed conv fused with the following <= 3-channel conv: its tap-projection weights
+    // second packing of the same kernel for the split-planar trunk (conv_trunk.hip): SRNet's 21 trunk convs in
+    // trunk_entries order; conv2d_transpose_1 in its usual order but with the k index <-> channel permutation of a
+    // split-planar input (kernels.h split_perm)
+    void* d_w2 = nullptr;
+    std::vector<PackEnt> ents2;
+    PackEnt* d_ents2 = nullptr;
     double wbytes = 0;
     // packing lists (kept for the device re-pack)
     std::vector<PackEnt> ents, proj_ents;
@@ -86,6 +92,11 @@ struct sr_ctx {
     int clip_B = 0, cur = 0;
     int trunk_sub = 0;   // clips per trunk sub-batch (0 = whole batch)
     int planar_trunk = 1;   // SRNet trunk activations (sx, sy) in 64-byte planes; SR_NO_PLANAR=1 disables
+    // bf16x3 only: trunk activations (s_in, sx, sy) split-planar, trunk convs by conv_trunk.hip.  1 = for steps of more than
+    // 65,536 pixels (small steps are launch bound: the resident-weight kernel reloads 72 KiB per workgroup per launch),
+    // 2 = always (SR_SPLIT_TRUNK=2, tests), 0 = never (SR_SPLIT_TRUNK=0)
+    int split_trunk = 1;
+    bool step_split = false;   // the step being enqueued uses it
     // two lanes: a step's batch is split into halves that run on `stream` and on `stream2` between a
     // fork and a join event, so one half's kernels fill the partial last round of workgroups (and the
     // under-filled low-resolution FNet launches) of the other.  SR_NO_DUAL=1 disables.
@@ -121,7 +132,9 @@ int fail(sr_ctx* c, int code, const char* fmt, ...);
 
 // weights
 void plan_layer(ConvLayer& L, int prec, int mode, int cin, int cout);
-std::vector<PackEnt> pack_entries(const ConvLayer& L, int prec, int kind);
+std::vector<PackEnt> pack_entries(const ConvLayer& L, int prec, int kind, bool kperm = false);
+std::vector<PackEnt> trunk_entries(int cin, int cout);
+int upload_alt(sr_ctx* c, ConvLayer& L, size_t bytes, const float* w);   // L.ents2 -> L.d_w2 (bf16x3)
 std::vector<PackEnt> proj_entries(int prec, int cout);
 size_t proj_bytes(int prec);
 int upload_layer(sr_ctx* c, ConvLayer& L, int prec, const float* w, const float* bias, int kind = PK_FWD);
@@ -167,6 +180,7 @@ struct ConvIO {
     int act;
     int in_planar = 0, out_planar = 0;   // kernels.h: planes of 64 B per pixel
     const void* proj_w = nullptr;        // transposed conv: fused tap projection, out = P [B,2H,2W,32] fp32
+    int in_split = 0;                    // transposed conv, bf16x3: planar input is split-planar; uses the layer's d_w2
     int res_mask = 0;                    // kernels.h ConvArgs::res_mask: res is the activation output to mask by
 };
 

@@ -89,3 +89,59 @@ def test_forced_lane_and_trunk_splits(sh, weights7, dtype, planar, lanes, sub):
             os.environ.pop(k, None)
     assert np.abs(got - want).max() <= 1e-3
     assert np.abs(lw - want_lw).max() <= 1e-3
+
+
+# ---- split-planar trunk (conv_trunk.hip): forced on for shapes that are too small to select it by themselves ------
+def _with_env(env, fn):
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("model", ["frvsr", "tecogan"])
+@pytest.mark.parametrize("h,w,B", [(8, 8, 1), (16, 40, 3), (24, 72, 2), (72, 24, 2), (8, 136, 1), (40, 64, 5)])
+def test_split_planar_trunk_on_ragged_shapes(sh, weights7, h, w, B, model):
+    """Tiles of 8 x 64 pixels: widths below / above / not a multiple of 64, a single tile row, several images
+    (a pair of workgroups walks tiles of different images), more XCD bands than tiles."""
+    lr_t, lr_tm1, est = step_inputs(700 + h + w, B, h, w)
+    want, want_lw = rt.generator_step(weights7, lr_t, lr_tm1, est, model=model)
+
+    def run():
+        ctx = sh.Context(h, w, max_batch=B, dtype="bf16x3", model=model)
+        ctx.load_weights(weights7)
+        out = ctx.step(lr_t, lr_tm1, est)
+        ctx.close()
+        return out
+
+    got, lw = _with_env({"SR_SPLIT_TRUNK": "2"}, run)
+    assert np.abs(got - want).max() <= 1e-3
+    assert np.abs(lw - want_lw).max() <= 1e-3
+    old, _ = _with_env({"SR_SPLIT_TRUNK": "0"}, run)
+    assert np.abs(got - old).max() <= 2e-4          # the two bf16x3 paths: same products, 16-bit trunk storage vs fp32
+
+
+def test_split_planar_trunk_follows_training(sh, weights7):
+    """An optimizer step re-packs every weight buffer on the device, the split-planar trunk's second packing
+    included: after two train_on_batch steps the forced-split step equals the classic path on the same ctx state."""
+    h, w, B = 16, 24, 2
+    lr_t, lr_tm1, est = step_inputs(77, B, h, w)
+    hr = np.random.default_rng(5).random((B, 4 * h, 4 * w, 3), dtype=np.float32)
+
+    def run():
+        ctx = sh.Context(h, w, max_batch=B, dtype="bf16x3")
+        ctx.load_weights(weights7)
+        before = ctx.step(lr_t, lr_tm1, est)[0]
+        for _ in range(2):
+            ctx.train_on_batch(lr_t, lr_tm1, est, hr, lr=1e-2)
+        after = ctx.step(lr_t, lr_tm1, est)[0]
+        ctx.close()
+        return before, after
+
+    b2, a2 = _with_env({"SR_SPLIT_TRUNK": "2"}, run)
+    b0, a0 = _with_env({"SR_SPLIT_TRUNK": "0"}, run)
+    assert np.abs(a0 - b0).max() > 1e-3             # the steps moved the weights visibly
+    assert np.abs(b2 - b0).max() <= 2e-4
+    assert np.abs(a2 - a0).max() <= 2e-4
