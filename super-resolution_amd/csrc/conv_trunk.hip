@@ -28,6 +28,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace sr {
 
@@ -66,6 +67,17 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 
 }  // namespace
 
+// RELU: ReLU after the bias; RES: add a.res after it.  NOMEM (ablation builds of the micro-benchmark only): 1 no tile
+// DMA, 2 no MFMAs, 4 no epilogue loads / stores.
+//
+// Software pipeline inside a wave: the epilogue of tile n (activation, residual, split into hi / lo, stores) is cut into
+// four pieces -- (M block, plane) -- and piece c runs inside the MFMA stream of plane c of tile n+1, on a copy of the
+// finished accumulators.  The two waves of a SIMD run this same program in lock step (one barrier per plane), so work
+// that is not interleaved with a wave's own MFMAs is not covered by its partner either: as separate phases the
+// epilogue VALU (about 750 instructions per wave and tile) and the DMA address arithmetic took as long as the MFMAs.
+// Everything in a plane's body is branch free so that it stays one scheduling region: lanes outside the image load
+// from / store to a dump area behind the tensor instead of being masked off.
+template <bool RELU, bool RES, int NOMEM>
 __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const wl = smem;                 // resident weights of this workgroup's channel half
@@ -89,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
     int t = xcd * per_xcd + pair;
     if (t >= t_end) return;
 
-    const size_t plane_bytes = (size_t)H * W * 64, img_bytes = plane_bytes * 4;   // the launcher keeps B * img_bytes < 4 GiB
+    const unsigned plane_bytes = (unsigned)(H * W * 64);   // the launcher keeps the whole tensor below 4 GiB: 32-bit offsets
 
     // ---- resident weights: 72 DMA instructions, 9 per wave
     {
@@ -101,12 +113,16 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
         }
     }
 
-    // ---- per-lane plan of the plane-tile DMA: instruction k = wave + 8 i moves units k*64 + lane
+    // ---- per-lane plan of the plane-tile DMA.  42 instructions of 1 KiB: wave w issues k = w + 8 i, i < 5, and a sixth
+    // one: k = w + 40 for waves 0, 1; the other waves repeat their fifth (same bytes to the same place) so that no wave
+    // branches
+    int kq[TK::PER_WAVE];
     int goff[TK::PER_WAVE];        // byte offset of the unit's source from the halo origin (row y0-1, column x0-1)
     int pyx[TK::PER_WAVE];         // halo column | halo row << 8; row 2^20: no such unit
 #pragma unroll
     for (int i = 0; i < TK::PER_WAVE; ++i) {
-        const int u = (wave + 8 * i) * 64 + lane;
+        kq[i] = wave + 8 * i < TK::NINST ? wave + 8 * i : wave + 8 * (i - 1);
+        const int u = kq[i] * 64 + lane;
         const int p = u >> 2, sl = (u & 3) ^ ((p >> 2) & 3);     // source unit of LDS unit (u & 3) of pixel p
         const int py = p / TK::HC, px = p - py * TK::HC;
         const bool exists = u < TK::NUNIT;
@@ -115,28 +131,58 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
         asm volatile("" : "+v"(goff[i]), "+v"(pyx[i]));          // keep them in registers: recomputing costs a division per DMA
     }
     const unsigned zoff = a.zero_off + (lane & 3) * 16;          // 64 zero bytes behind the tensor: halo outside the image
-    // addresses are a.in + 32-bit offset (the tensor is < 4 GiB): SGPR base + one VGPR per DMA
-    auto issue = [&](int tt, int c, int buf) {
+    const unsigned dump = a.zero_off + 256 + lane * 32;          // where lanes outside the image load / store
+    struct Tile {
+        unsigned off0;      // offset of the halo origin of plane 0 (wraps for row -1 / column -1: only in-image units use it)
+        unsigned okm;       // bit i: this lane's unit of DMA instruction i lies inside the image
+        unsigned eoff[2];   // epilogue: offset of this lane's record of (M block, first plane of this half), or `dump`
+        unsigned estep;     // + this for the second plane (0 for dump lanes)
+    };
+    auto locate = [&](int tt) {
+        Tile q;
         const int b = tt / per_img;
         const int rem = tt - b * per_img;
         const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
         const int y0 = ty * TK::TH - 1, x0 = tx * TK::TWX - 1;
-        const unsigned tile_off = (unsigned)(b * 4 + c) * (unsigned)plane_bytes + (unsigned)((y0 * W + x0) * 64);   // wraps for y0 = -1: only valid units use it
+        q.off0 = (unsigned)(b * 4) * plane_bytes + (unsigned)((y0 * W + x0) * 64);
+        q.okm = 0;
+#pragma unroll
+        for (int i = 0; i < TK::PER_WAVE; ++i) {
+            const unsigned gy = (unsigned)(y0 + (pyx[i] >> 8)), gx = (unsigned)(x0 + (pyx[i] & 255));
+            q.okm |= ((gy < (unsigned)H) & (gx < (unsigned)W)) ? (1u << i) : 0u;   // a unit that does not exist fails the row test
+        }
+        const int y = y0 + 1 + wave;
+        const unsigned row = (unsigned)(b * 4 + 2 * half) * plane_bytes + (unsigned)(y * W) * 64u + 32u * h;
+        bool any = false;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int x = x0 + 1 + mb * 32 + r;
+            const bool ok = y < H && x < W;
+            q.eoff[mb] = ok ? row + (unsigned)x * 64u : dump;
+            any |= ok;
+        }
+        q.estep = (y < H && x0 + 1 + r < W) ? plane_bytes : 0u;   // lane r of block 1 is inside only if lane r of block 0 is
+        return q;
+    };
+    // addresses are a.in + 32-bit offset: SGPR base + one VGPR per DMA
+    auto issue = [&](const Tile& q, int c, int buf) {
+        if (NOMEM & 1) return;
+        const unsigned offc = q.off0 + (unsigned)c * plane_bytes;
         unsigned char* dst = abuf + buf * TK::A_BYTES;
 #pragma unroll
         for (int i = 0; i < TK::PER_WAVE; ++i) {
-            const int k = wave + 8 * i;
-            if (k < TK::NINST && !(a.dbg & 1)) {   // wave-uniform
-                const unsigned gy = (unsigned)(y0 + (pyx[i] >> 8)), gx = (unsigned)(x0 + (pyx[i] & 255));
-                const bool ok = (gy < (unsigned)H) & (gx < (unsigned)W);   // a unit that does not exist fails the row test
-                const unsigned off = ok ? tile_off + (unsigned)goff[i] : zoff;
-                __builtin_amdgcn_global_load_lds((const SR_AS1 void*)(a.in + off), (SR_AS3 void*)(dst + k * 1024), 16, 0, 0);
-            }
+            const unsigned off = ((q.okm >> i) & 1u) ? offc + (unsigned)goff[i] : zoff;
+            __builtin_amdgcn_global_load_lds((const SR_AS1 void*)(a.in + off), (SR_AS3 void*)(dst + kq[i] * 1024), 16, 0, 0);
         }
     };
-    issue(t, 0, 0);
+    Tile cur = locate(t);
+    issue(cur, 0, 0);
 
-    // ---- fragment addresses (bytes from the start of a plane tile / of the weights)
+    // the bias of this lane's 16 channels: lane (pixel r, h) owns channels 32 half + 8 g + 4 h + (0..3)
+    f32x4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const f32x4*>(a.bias + 32 * half + 8 * g + 4 * h);
+
     // B operand = pixels: lane (r, h) reads unit 2h (hi) and 2h+1 (lo) of halo pixel (wave + ky, 32 mb + r + kx)
     auto a_addr = [&](int ky, int kx, int mb) {
         const int p = (wave + ky) * TK::HC + mb * 32 + r + kx;
@@ -144,35 +190,82 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
     };
     const unsigned char* const bl = wl + lane * 16;
 
-    const float slope = a.relu ? 0.f : 1.f;
-    int q = 0;            // running count of (tile, plane) steps: buffer = q & 1
-    int nst = 0;          // vector stores this wave issued in the previous tile's epilogue, after its last DMA
+    // One piece of a finished tile's epilogue: M block mb, plane pl of this half = 8 channels of this lane = 4 packed pairs.
+    // ep_load issues the residual loads (inline asm: the compiler would wait vmcnt(0) for an ordinary load while DMA is in
+    // flight, draining the prefetch), ep_pair computes pair k, ep_store stores; the plane step spreads them over its taps.
+    struct Piece {
+        u32x4 rh, rl, oh, ol;
+        unsigned off;
+    };
+    auto ep_load = [&](Piece& pc, unsigned off) {
+        pc.off = off;
+        if (RES && !(NOMEM & 4)) {
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pc.rh) : "v"(off), "s"(a.res) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(pc.rl) : "v"(off), "s"(a.res) : "memory");
+        } else {
+            pc.rh = pc.rl = u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    // the residual loads are older than the NDMA DMA instructions of the step that issued them
+    auto ep_wait = [&](Piece& pc, auto ndma) {
+        constexpr int N = decltype(ndma)::value;
+        if (RES && !(NOMEM & 4)) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(pc.rh), "+v"(pc.rl) : "n"(N));
+    };
+    auto ep_pair = [&](Piece& pc, float v0, float v1, int k) {
+        if (RELU) {
+            v0 = fmaxf(v0, 0.f);
+            v1 = fmaxf(v1, 0.f);
+        }
+        if (RES) {
+            v0 += bf_even(pc.rh[k]) + bf_even(pc.rl[k]);
+            v1 += bf_odd(pc.rh[k]) + bf_odd(pc.rl[k]);
+        }
+        pc.oh[k] = pack_bf16(v0, v1);
+        pc.ol[k] = pack_bf16(v0 - bf_even(pc.oh[k]), v1 - bf_odd(pc.oh[k]));
+    };
+    auto ep_store = [&](Piece& pc) {
+        if (!(NOMEM & 4)) {
+            *reinterpret_cast<u32x4*>(a.out + pc.off) = pc.oh;
+            *reinterpret_cast<u32x4*>(a.out + pc.off + 16) = pc.ol;
+        } else {
+            asm volatile("" ::"v"(pc.oh), "v"(pc.ol));
+        }
+    };
+
+    f32x16 acc[2], fin[2];      // running tile; finished tile whose epilogue is being drained
+    Tile done;                  // where `fin` goes
+    done.eoff[0] = done.eoff[1] = dump;
+    done.estep = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) fin[0][i] = fin[1][i] = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weights and the first plane tile
+    int q = 0;                  // running count of (tile, plane) steps: buffer = q & 1
     for (;;) {
         const int tn = t + npairs;
         const bool have_next = tn < t_end;
-        f32x16 acc[2];
-        {   // the accumulators start from the bias: lane (pixel r, h) owns channels 32 half + 8 g + 4 h + (0..3)
+        const Tile nxt = locate(have_next ? tn : t);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + 32 * half + 8 * g + 4 * h);
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[0][4 * g + j] = acc[1][4 * g + j] = bv[j];
-            }
-        }
-#pragma unroll 1
-        for (int c = 0; c < 4; ++c, ++q) {
-            // this wave's DMA of step q has landed.  vmcnt counts in issue order, so after a full epilogue (8 stores
-            // issued behind the DMA) the stores may stay in flight; any other case drains everything
-            if (c == 0 && nst == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int j = 0; j < 4; ++j) acc[0][4 * g + j] = acc[1][4 * g + j] = bias4[g][j];
+
+        auto plane_step = [&](auto cc) {
+            constexpr int C = decltype(cc)::value;
+            constexpr int mbp = C >> 1, plp = C & 1;    // the piece of the finished tile that drains under this step
+            // The DMA of this step has landed: vmcnt counts in issue order and the only younger operations are the two
+            // stores of the previous step's epilogue piece (none in the ablation build without them).
+            if (NOMEM & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             __builtin_amdgcn_s_barrier();           // every wave's part landed; every wave is done reading the other buffer
             asm volatile("" ::: "memory");
-            if (c < 3) issue(t, c + 1, (q + 1) & 1);
-            else if (have_next) issue(tn, 0, (q + 1) & 1);
-
+            Piece pc;
+            ep_load(pc, done.eoff[mbp] + (plp ? done.estep : 0u));     // before the DMA: older in the vmcnt queue
+            if (C < 3) issue(cur, C + 1, (q + 1) & 1);
+            else issue(nxt, 0, (q + 1) & 1);        // past the last tile: re-reads this tile's first plane, harmless
             const unsigned char* at = abuf + (q & 1) * TK::A_BYTES;
-            const unsigned char* bw = bl + c * (9 * 2 * 1024);
-            if (a.dbg & 2) continue;
+            const unsigned char* bw = bl + C * (9 * 2 * 1024);
+            ++q;
             u32x4 fa[2][2][2], fb[2][2];            // [buffer][M block][hi, lo], [buffer][hi, lo]
             auto load_tap = [&](int tap, int s) {
                 const int ky = tap / 3, kx = tap - 3 * ky;
@@ -185,80 +278,64 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
                 fb[s][0] = *reinterpret_cast<const u32x4*>(bw + (tap * 2 + 0) * 1024);
                 fb[s][1] = *reinterpret_cast<const u32x4*>(bw + (tap * 2 + 1) * 1024);
             };
-            load_tap(0, 0);
+            if (!(NOMEM & 2)) load_tap(0, 0);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int s = tap & 1;
-                if (tap + 1 < 9) load_tap(tap + 1, s ^ 1);
-                const bf16x8 wh = __builtin_bit_cast(bf16x8, fb[s][0]), wlo = __builtin_bit_cast(bf16x8, fb[s][1]);
+                if (!(NOMEM & 2)) {
+                    if (tap + 1 < 9) load_tap(tap + 1, s ^ 1);
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, fb[s][0]), wlo = __builtin_bit_cast(bf16x8, fb[s][1]);
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-                    const bf16x8 xh = __builtin_bit_cast(bf16x8, fa[s][mb][0]), xl = __builtin_bit_cast(bf16x8, fa[s][mb][1]);
-                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[mb], 0, 0, 0);
-                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xh, acc[mb], 0, 0, 0);
-                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[mb], 0, 0, 0);
-                }
-                if (tap + 1 < 9) {   // one LDS read behind each MFMA
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    for (int mb = 0; mb < 2; ++mb) {
+                        const bf16x8 xh = __builtin_bit_cast(bf16x8, fa[s][mb][0]), xl = __builtin_bit_cast(bf16x8, fa[s][mb][1]);
+                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[mb], 0, 0, 0);
+                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xh, acc[mb], 0, 0, 0);
+                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[mb], 0, 0, 0);
                     }
+                }
+                // the epilogue piece, spread over the taps: pair k under tap 3 + k, the stores under tap 7
+                if (tap == 3) ep_wait(pc, std::integral_constant<int, (NOMEM & 1) ? 0 : TK::PER_WAVE>{});
+                if (tap >= 3 && tap < 7) {
+                    const int k = tap - 3;
+                    ep_pair(pc, fin[mbp][8 * plp + 2 * k], fin[mbp][8 * plp + 2 * k + 1], k);
+                }
+                if (tap == 7) ep_store(pc);
+                // one fragment read of the next tap and a few VALU / DMA instructions behind each MFMA
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (tap + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (tap == 0) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    if (tap == 0) __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        // ---- epilogue: activation, residual, split, two 16-byte stores per (M block, plane)
-        {
-            const int b = t / per_img;
-            const int rem = t - b * per_img;
-            const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
-            const int y = ty * TK::TH + wave;
-            // a store instruction is issued when at least one of its lanes is inside the image (wave-uniform count)
-            nst = (y < H && !(a.dbg & 4)) ? (tx * TK::TWX + 32 < W ? 8 : 4) : 0;
-            const size_t row_off = (size_t)b * img_bytes + (size_t)(2 * half) * plane_bytes + (size_t)y * W * 64 + 32 * h;
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const int x = tx * TK::TWX + mb * 32 + r;
-                const bool ok = y < H && x < W;
-                const size_t off = row_off + (size_t)x * 64;
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float tv = acc[mb][8 * pl + e];      // g = 2 pl + (e >> 2), j = e & 3
-                        v[e] = fmaxf(tv, slope * tv);
-                    }
-                    const size_t o = off + (size_t)pl * plane_bytes;
-                    if (a.res) {
-                        u32x4 rh = {0u, 0u, 0u, 0u}, rl = {0u, 0u, 0u, 0u};
-                        if (ok && !(a.dbg & 4)) {
-                            rh = *reinterpret_cast<const u32x4*>(a.res + o);
-                            rl = *reinterpret_cast<const u32x4*>(a.res + o + 16);
-                        }
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            v[2 * k] += bf_even(rh[k]) + bf_even(rl[k]);
-                            v[2 * k + 1] += bf_odd(rh[k]) + bf_odd(rl[k]);
-                        }
-                    }
-                    u32x4 oh, ol;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        oh[k] = pack_bf16(v[2 * k], v[2 * k + 1]);
-                        ol[k] = pack_bf16(v[2 * k] - bf_even(oh[k]), v[2 * k + 1] - bf_odd(oh[k]));
-                    }
-                    if (ok && (!(a.dbg & 4) || oh[0] == 0x12345678u)) {
-                        *reinterpret_cast<u32x4*>(a.out + o) = oh;
-                        *reinterpret_cast<u32x4*>(a.out + o + 16) = ol;
-                    }
-                }
-            }
-        }
+        };
+        plane_step(std::integral_constant<int, 0>{});
+        plane_step(std::integral_constant<int, 1>{});
+        plane_step(std::integral_constant<int, 2>{});
+        plane_step(std::integral_constant<int, 3>{});
+        fin[0] = acc[0];
+        fin[1] = acc[1];
+        done = cur;
         if (!have_next) break;
         t = tn;
+        cur = nxt;
     }
+    // the last tile's epilogue has no MFMAs to hide under
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            Piece pc;
+            ep_load(pc, done.eoff[mb] + (pl ? done.estep : 0u));
+            ep_wait(pc, std::integral_constant<int, 0>{});
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ep_pair(pc, fin[mb][8 * pl + 2 * k], fin[mb][8 * pl + 2 * k + 1], k);
+            ep_store(pc);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing DMA (into LDS) must not outlive the workgroup
 }
 
 static int trunk_num_cus() {
@@ -274,16 +351,24 @@ static int trunk_num_cus() {
 
 size_t trunk_weight_bytes() { return (size_t)2 * TK::W_BYTES; }
 
-hipError_t launch_trunk_conv(TrunkArgs a, hipStream_t s) {
+template <bool RELU, bool RES, int NOMEM>
+static hipError_t launch_trunk_t(const TrunkArgs& a, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trunk_conv_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trunk_conv_kernel<RELU, RES, NOMEM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, TK::LDS);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
+    hipLaunchKernelGGL((trunk_conv_kernel<RELU, RES, NOMEM>), dim3(grid), dim3(512), TK::LDS, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_trunk_conv(TrunkArgs a, hipStream_t s) {
     if (a.B < 1 || a.H < 1 || a.W < 1 || !a.in || !a.out || !a.wpack || !a.bias) return hipErrorInvalidValue;
-    if ((double)a.B * a.H * a.W * 256.0 + 64.0 > 4294967295.0 || (double)a.zero_off + 64.0 > 4294967295.0) return hipErrorInvalidValue;
+    // 32-bit offsets: the tensor, its 256 zero bytes and the 2 KiB dump area behind them
+    if ((double)a.B * a.H * a.W * 256.0 + 4096.0 > 4294967295.0 || (double)a.zero_off + 4096.0 > 4294967295.0) return hipErrorInvalidValue;
+    if ((a.relu != 0) == (a.res != nullptr)) return hipErrorInvalidValue;   // the trunk has ReLU layers and residual layers, nothing else
     a.tiles_x = (a.W + TK::TWX - 1) / TK::TWX;
     a.tiles_y = (a.H + TK::TH - 1) / TK::TH;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
@@ -294,8 +379,19 @@ hipError_t launch_trunk_conv(TrunkArgs a, hipStream_t s) {
     // even out the rounds: every pair the same number of tiles (+-1)
     const int rounds = (per_xcd + npairs - 1) / npairs;
     npairs = (per_xcd + rounds - 1) / rounds;
-    hipLaunchKernelGGL(trunk_conv_kernel, dim3(16 * npairs), dim3(512), TK::LDS, s, a);
-    return hipGetLastError();
+    const int grid = 16 * npairs;
+    if (a.dbg) {   // micro-benchmark ablations (tools/trunk_ablate.sh), residual layer only
+        switch (a.dbg & 7) {
+            case 1: return launch_trunk_t<false, true, 1>(a, grid, s);
+            case 2: return launch_trunk_t<false, true, 2>(a, grid, s);
+            case 3: return launch_trunk_t<false, true, 3>(a, grid, s);
+            case 4: return launch_trunk_t<false, true, 4>(a, grid, s);
+            case 5: return launch_trunk_t<false, true, 5>(a, grid, s);
+            case 6: return launch_trunk_t<false, true, 6>(a, grid, s);
+            default: return launch_trunk_t<false, true, 7>(a, grid, s);
+        }
+    }
+    return a.res ? launch_trunk_t<false, true, 0>(a, grid, s) : launch_trunk_t<true, false, 0>(a, grid, s);
 }
 
 }  // namespace sr

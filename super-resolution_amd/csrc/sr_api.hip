@@ -356,11 +356,12 @@ int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, con
 }
 
 
-// every buffer is followed by 256 zero bytes: conv_trunk.hip reads the halo pixels that lie outside the image from there
+// every buffer is followed by 256 zero bytes (conv_trunk.hip reads the halo pixels that lie outside the image from there)
+// and a 2 KiB dump area (where its lanes outside the image load and store); 4 KiB in all
 int alloc_buf(sr_ctx* c, const char* name, size_t bytes) {
     void* p = nullptr;
-    HIPCHK(c, hipMalloc(&p, bytes + 256));
-    HIPCHK(c, hipMemset((unsigned char*)p + bytes, 0, 256));
+    HIPCHK(c, hipMalloc(&p, bytes + 4096));
+    HIPCHK(c, hipMemset((unsigned char*)p + bytes, 0, 4096));
     c->buf[name] = p;
     c->buf_img_bytes[name] = bytes / (size_t)c->max_batch;
     return SR_OK;
@@ -492,7 +493,7 @@ int run_srnet(sr_ctx* c, int B, float* d_out, bool split) {
                 TrunkArgs ta = {in, out, res, (const unsigned char*)L.d_w2, L.d_bias, (unsigned)tail, nb, H, W, relu, 0, 0, 0};
                 const double px = (double)nb * H * W;
                 ProfScope ps(c, name, px * 9.0 * L.cin * L.cout * 2.0, px * 256.0 * (res ? 3 : 2) + (double)trunk_weight_bytes());
-                if (tail + 64 > 4294967295.0) return fail(c, SR_ERR_ARG, "%s: tensor too large for 32-bit offsets", name);
+                if (tail + 4096 > 4294967295.0) return fail(c, SR_ERR_ARG, "%s: tensor too large for 32-bit offsets", name);
                 LAUNCHCHK(c, name, launch_trunk_conv(ta, st));
                 return SR_OK;
             };
@@ -1239,13 +1240,13 @@ int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, in
         L.ents2 = trunk_entries(64, 64);
         if ((rc = upload_alt(nullptr, L, trunk_weight_bytes(), w.data()))) return rc;
         const size_t bytes = npix * 256;
-        unsigned char* bufs[2] = {(unsigned char*)d.get(bytes + 256), (unsigned char*)d.get(bytes + 256)};
+        unsigned char* bufs[2] = {(unsigned char*)d.get(bytes + 4096), (unsigned char*)d.get(bytes + 4096)};
         if (!bufs[0] || !bufs[1]) return fail(nullptr, SR_ERR_HIP, "hipMalloc failed");
-        std::vector<uint16_t> hb((bytes + 256) / 2);
+        std::vector<uint16_t> hb((bytes + 4096) / 2);
         for (size_t i = 0; i < bytes / 2; ++i) hb[i] = f2bf(rnd() * ((i / 8) & 1 ? 0.004f : 1.f));   // units alternate hi | lo
-        for (int k = 0; k < 2; ++k) HIPCHK(nullptr, hipMemcpy(bufs[k], hb.data(), bytes + 256, hipMemcpyHostToDevice));
+        for (int k = 0; k < 2; ++k) HIPCHK(nullptr, hipMemcpy(bufs[k], hb.data(), bytes + 4096, hipMemcpyHostToDevice));
         TrunkArgs ta = {bufs[0], bufs[1], residual ? bufs[1] : nullptr, (const unsigned char*)L.d_w2, L.d_bias, (unsigned)bytes,
-                        B, H, W, 1, 0, 0, g_conv_dbg};
+                        B, H, W, residual ? 0 : 1, 0, 0, g_conv_dbg};
         hipEvent_t e0, e1;
         HIPCHK(nullptr, hipEventCreate(&e0));
         HIPCHK(nullptr, hipEventCreate(&e1));
