@@ -236,6 +236,57 @@ int sr_op_resize_bilinear_bwd(int device, int B, int H, int W, int C, int s, con
 int sr_op_warp_bwd_flow(int device, int B, int H, int W, int C, const float* img, const float* flow,
                         const float* g, float* gflow);
 
+/* ---- TecoGAN discriminator and adversarial step (SURVEY.md section 8 f, rank 3) -------------------------------
+ * sr_disc replaces the Keras model of reference layers.py:142-186 (built at TecoGAN.py:60): nine HR images (B,H,W,3)
+ * [hr_past, hr_pres, hr_fut, warp_past, warp_pres, warp_fut, bic_past, bic_pres, bic_fut] -> concat 27 -> Conv2D 3x3 64 +
+ * LeakyReLU(0.2) -> 4 x [Conv2D 4x4 strides 2 'same' + BatchNormalization (epsilon 1e-3, momentum 0.99) + LeakyReLU(0.2)]
+ * with 64 / 64 / 128 / 256 filters -> Flatten -> Dense(1) -> sigmoid; outputs the probability and the four feature maps.
+ * H, W multiples of 16; dtype fp32 or bf16x3.  The 28 tensors in Discriminator.save_weights order: conv2d (kernel, bias),
+ * 4 x [conv2d (kernel (4,4,Cin,Cout), bias), batch_normalization (gamma, beta, moving_mean, moving_variance)], dense
+ * (kernel (H/16*W/16*256, 1), bias). */
+typedef struct sr_disc sr_disc;
+const char* sr_disc_last_error(const sr_disc* d);
+int sr_disc_create(sr_disc** out, int device, int H, int W, int max_batch, int dtype);
+int sr_disc_destroy(sr_disc* d);
+int sr_disc_sync(sr_disc* d);
+int sr_disc_tensor_count(void);
+int sr_disc_param_count(const sr_disc* d, int64_t* n);
+/* discriminator.load_weights / save_weights (reference TecoGAN.py:161,518): tensor `index` (0..27) in file order */
+int sr_disc_set_tensor(sr_disc* d, int index, const float* host, const int64_t* shape, int rank);
+int sr_disc_commit(sr_disc* d);
+int sr_disc_get_tensor(sr_disc* d, int index, char* name_out, int name_cap, float* host_out, int64_t* shape_out, int* rank_out);
+/* discriminator.predict (reference TecoGAN.py:446,467): BatchNormalization in inference mode (moving statistics).
+ * imgs: 9 host pointers; prob (B); feats: 4 host pointers (B,H/2,W/2,64) ... (B,H/16,W/16,256); the array or entries may be NULL */
+int sr_disc_predict(sr_disc* d, int B, const float* const* imgs, float* prob, float* const* feats);
+/* discriminator.train_on_batch (reference TecoGAN.py:436-458) up to the optimizer: loss = binary_crossentropy(D_st, labels)
+ * (Keras: probability clipped to [1e-7, 1-1e-7]; the feature-map outputs carry loss weight 0), BatchNormalization in
+ * training mode, moving statistics updated; the flat gradient (28 tensors in file order, zeros for the moving statistics)
+ * stays on the device.  sr_disc_read_grads copies it to the host or to a DEVICE buffer (out_on_device = 1: the all-reduce
+ * buffer of a data-parallel job).  sr_disc_apply = Keras-2.2.4 Adam with iteration `t` (the value AFTER this step: the
+ * reference shares one Adam instance between generator, discriminator and tecogan, TecoGAN.py:111-131, so the caller owns
+ * the counter) from d_grads * grad_scale (DEVICE; NULL = own gradient), moment slot 0 (discriminator.train_on_batch) or
+ * 1 (tecogan.train_on_batch); reset_moments zeroes the slot first (the reference re-compiles the discriminator every
+ * iteration, TecoGAN.py:436, which gives its train function fresh Adam slots). */
+int sr_disc_train_grads(sr_disc* d, int B, const float* const* imgs, const float* labels, float* loss);
+int sr_disc_read_grads(sr_disc* d, float* out, int out_on_device);
+int sr_disc_apply(sr_disc* d, const float* d_grads, float grad_scale, float lr, float beta1, float beta2, float eps, int64_t t,
+                  int slot, int reset_moments);
+/* tecogan.train_on_batch (reference TecoGAN.py:87-108,122-131,469-479) up to the optimizer, ctx model SR_TECOGAN:
+ * inputs [lr_t, lr_tm1, est_tm1, next_est (I_hr_fut), next_hat_est (I_hr_warp_fut), bic_past, bic_pres, bic_fut], targets
+ * [hr_t, ones, d_1..d_4 (d_targets: 4 host pointers), hr_t x 4 (VGG19 terms: ImageNet weights are a download, the terms
+ * count as 0), pp_target (the batch-flipped hr_t), lr_t]; loss_weights: the 12 of TecoGAN.py:127-130 (the warp weight must
+ * be 1); losses[13] = total + the 12 unweighted parts in Keras' order.  BatchNormalization runs in training mode (learning
+ * phase 1) without touching the moving statistics.  Generator gradient -> the ctx (sr_train_read_grads), discriminator
+ * gradient -> the discriminator (sr_disc_read_grads).  sr_tecogan_apply: Adam step `t` on the generator (moments of tecogan's
+ * own train function) and, with train_disc != 0, on the discriminator: the reference compiles tecogan before it ever sets
+ * discriminator.trainable = False (TecoGAN.py:122 vs :461), so Keras 2.2.4 keeps the discriminator's weights among
+ * tecogan's collected trainable weights. */
+int sr_tecogan_grads(sr_ctx* ctx, sr_disc* d, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1,
+                     const float* next_est, const float* next_hat_est, const float* bic_past, const float* bic_pres,
+                     const float* bic_fut, const float* hr_t, const float* const* d_targets, const float* pp_target,
+                     const float* loss_weights, float* losses);
+int sr_tecogan_apply(sr_ctx* ctx, sr_disc* d, float lr, float beta1, float beta2, float eps, int64_t t, int train_disc);
+
 /* The ONE entry point that allocates nothing.  It has no counterpart in the reference; it exists for callers
  * that cannot call hipMalloc: code under HIP graph capture, tight training loops, harnesses that forbid
  * allocation.  It is sr_op_conv3x3_bwd's kernel / bias gradient (dw (3,3,Cin,Cout) HWIO, db (Cout,), db may be

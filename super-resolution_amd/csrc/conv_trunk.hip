@@ -153,13 +153,11 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
         }
         const int y = y0 + 1 + wave;
         const unsigned row = (unsigned)(b * 4 + 2 * half) * plane_bytes + (unsigned)(y * W) * 64u + 32u * h;
-        bool any = false;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const int x = x0 + 1 + mb * 32 + r;
             const bool ok = y < H && x < W;
             q.eoff[mb] = ok ? row + (unsigned)x * 64u : dump;
-            any |= ok;
         }
         q.estep = (y < H && x0 + 1 + r < W) ? plane_bytes : 0u;   // lane r of block 1 is inside only if lane r of block 0 is
         return q;

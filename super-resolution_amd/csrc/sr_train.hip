@@ -9,6 +9,7 @@
 //   conv_tapsn.hip); the data gradient is the same convolution with mirrored, transposed weights
 //   weight gradients, transposed-conv data gradient, gathers: train_kernels.hip
 #include "sr_internal.h"
+#include "sr_disc.h"
 
 #include <cmath>
 #include <cstdio>
@@ -21,6 +22,7 @@ struct sr_train_state {
     int64_t off[77] = {0};              // offsets of the 76 tensors in the flat vectors
     float *d_params = nullptr, *d_m = nullptr, *d_v = nullptr, *d_grad = nullptr;
     int64_t t = 0;                      // optimizer iterations
+    float *d_m2 = nullptr, *d_v2 = nullptr;   // Adam moments of the generator inside tecogan.train_on_batch (its own train function)
     bool host_stale = false;            // ctx->tensors older than d_params
     ConvLayer fnet_dg[14], srnet_dg[24];   // data-gradient convs of the Conv2D layers (planned where needed)
     std::map<std::string, float*> act;  // saved activations and gradient work buffers
@@ -171,6 +173,11 @@ struct Tape {
     std::vector<WgradArgs> pending;   // weight gradients whose slice partials wait for reduce_all()
     size_t part_off = 0;
     size_t b0 = 0;                    // first image of the slice of the batch this tape works on (forward only)
+    // combined TecoGAN step: the forward also writes the warped previous estimate; the backward starts from a gradient of
+    // the output that the caller has already put into "g_est" and adds the discriminator's gradient of that warped estimate
+    float* hr_warp_out = nullptr;
+    bool ext_g_est = false;
+    const float* g27 = nullptr;
     float* a(const char* n) { return T->act[n] + b0 * T->act_img[n]; }
 
     int conv(const ConvLayer& L, const float* in, int H, int W, float* out, int out_cs, int cout_store, int act,
@@ -269,7 +276,7 @@ int train_forward(Tape& t, int stage, const float* d_lr_t, const float* d_lr_tm1
     }
     // warps
     LAUNCHCHK(c, "lr_warp", launch_warp3(d_lr_tm1, d_flow, d_lr_warp, B, H, W, st));
-    LAUNCHCHK(c, "pre_srnet", launch_pre_srnet(d_flow, d_est_prev, d_lr_t, t.a("s_in"), nullptr, 0, B, H, W, st));
+    LAUNCHCHK(c, "pre_srnet", launch_pre_srnet(d_flow, d_est_prev, d_lr_t, t.a("s_in"), t.hr_warp_out, 0, B, H, W, st));
     // SRNet
     const ConvLayer* S = c->srnet;
     char xn[16], yn[16], xn1[16];
@@ -307,8 +314,9 @@ int train_backward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const fl
     const ConvLayer* SD = T->srnet_dg;
     const int so = 28;   // index of SRNet's first tensor
     // ---- losses (Keras: mean over all elements) and their gradients
-    LAUNCHCHK(c, "mse", launch_mse_grad(d_est, d_hr, t.a("g_est"), T->mse_part, T->d_loss, 16 * L0, 3, 4,
-                                           c->model == SR_TECOGAN ? t.a("s_out") : d_est, c->model == SR_TECOGAN, st));
+    if (!t.ext_g_est)
+        LAUNCHCHK(c, "mse", launch_mse_grad(d_est, d_hr, t.a("g_est"), T->mse_part, T->d_loss, 16 * L0, 3, 4,
+                                               c->model == SR_TECOGAN ? t.a("s_out") : d_est, c->model == SR_TECOGAN, st));
     // ---- SRNet, reverse order (reference layers.py:66-76)
     RC(t.wgrad(so + 46, M_CONV, 64, 3, t.a("up2"), 64, t.a("g_est"), 4, 4 * H, 4 * W));
     {   // data gradient of the 64->3 conv with up2's ReLU mask in the store: one pass over the step's largest tensor
@@ -351,6 +359,7 @@ int train_backward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const fl
     // ---- warps: gradient w.r.t. the flow only (the previous estimate and LR frame are constants)
     {
         ProfScope ps(c, "train.warp_bwd", 0, (double)L0 * 16 * (12 + 12 + 8) + (double)L0 * 256);
+        if (t.g27) LAUNCHCHK(c, "add_hat_s2d", launch_add_hat_s2d(t.g27, cur, B, H, W, 64, st));
         LAUNCHCHK(c, "hr_warp_bwd", launch_hr_warp_bwd(d_est_prev, d_flow, cur, t.a("g_fhr"), B, H, W, 64, st));
         HIPCHK(c, hipMemsetAsync(t.a("g_flow"), 0, (size_t)L0 * 16 * 4, st));
         LAUNCHCHK(c, "resize_bwd", launch_resize_bwd(t.a("g_fhr"), t.a("g_flow"), B, H, W, 2, 4, 16, 0, nullptr, A_NONE, st));
@@ -539,7 +548,7 @@ namespace srh {
 void train_free(sr_ctx* c) {
     sr_train_state* T = c->train;
     if (!T) return;
-    float* fl[] = {T->d_params, T->d_m, T->d_v, T->d_grad, T->part, T->d_loss};
+    float* fl[] = {T->d_params, T->d_m, T->d_v, T->d_grad, T->part, T->d_loss, T->d_m2, T->d_v2};
     for (auto p : fl)
         if (p) (void)hipFree(p);
     if (T->mse_part) (void)hipFree(T->mse_part);
@@ -825,6 +834,129 @@ int sr_op_warp_bwd_flow(int device, int B, int H, int W, int C, const float* img
     LAUNCHCHK(nullptr, "warp_bwd_flow", launch_warp_bwd_flow(d_i, d_f, d_g, d_o, B, H, W, C, 2, 0, nullptr));
     HIPCHK(nullptr, hipDeviceSynchronize());
     HIPCHK(nullptr, hipMemcpy(gflow, d_o, npix * 2 * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// tecogan.train_on_batch (reference TecoGAN.py:87-108 graph, :122-131 losses, :469-479 call) up to the optimizer: the
+// generator's forward, the discriminator on [est_tm1, est, next_est, warp(est_tm1), est, next_hat_est, bic_past,
+// bic_pres, bic_fut] with BatchNormalization in training mode (Keras learning phase 1), the twelve weighted losses
+// (the four VGG19 terms need ImageNet weights, a download: they count as 0 and their weights are ignored) and the
+// backward through both networks.  Generator gradient -> the ctx's flat vector (sr_train_read_grads / sr_train_grads'
+// layout), discriminator gradient -> the discriminator's (sr_disc_read_grads).
+int sr_tecogan_grads(sr_ctx* c, sr_disc* d, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1,
+                     const float* next_est, const float* next_hat_est, const float* bic_past, const float* bic_pres,
+                     const float* bic_fut, const float* hr_t, const float* const* d_targets, const float* pp_target,
+                     const float* loss_weights, float* losses) {
+    int rc = check_ready(c, B);
+    if (rc) return rc;
+    if (!d) return fail(c, SR_ERR_ARG, "discriminator is NULL");
+    if (c->model != SR_TECOGAN) return fail(c, SR_ERR_STATE, "the combined step needs a ctx created with model SR_TECOGAN");
+    if (c->pad) return fail(c, SR_ERR_STATE, "training needs a ctx whose tile size is a multiple of 8");
+    if (!d->committed) return fail(c, SR_ERR_WEIGHTS, "the discriminator's weights are not committed");
+    if (d->device != c->device || d->H != 4 * c->h || d->W != 4 * c->w || B > d->max_batch)
+        return fail(c, SR_ERR_ARG, "discriminator (%dx%d, max batch %d, device %d) does not fit this generator", d->H, d->W, d->max_batch, d->device);
+    if (!lr_t || !lr_tm1 || !est_tm1 || !next_est || !next_hat_est || !bic_past || !bic_pres || !bic_fut || !hr_t || !d_targets ||
+        !pp_target || !loss_weights)
+        return fail(c, SR_ERR_ARG, "NULL tensor pointer");
+    const float* lw = loss_weights;
+    if (lw[11] != 1.f) return fail(c, SR_ERR_ARG, "the warp loss weight must be 1 (reference TecoGAN.py:130); other values are not built");
+    if ((rc = train_init(c))) {
+        train_free(c);
+        return rc;
+    }
+    sr_train_state* T = c->train;
+    c->clip_active = false;
+    hipStream_t st = c->stream;
+    const int H = c->h, W = c->w;
+    const size_t nlr = (size_t)B * H * W * 3 * 4, nhr = nlr * 16;
+    if (!T->act.count("pp") && (rc = talloc(c, "pp", (size_t)c->max_batch * H * W * 48))) return rc;
+    // everything of this call runs on the generator's stream, the discriminator's kernels included
+    HIPCHK(c, hipStreamSynchronize(d->stream));
+    struct StreamSwap {
+        sr_disc* d;
+        hipStream_t old;
+        ~StreamSwap() { d->stream = old; }
+    } swap_guard{d, d->stream};
+    d->stream = st;
+    HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, lr_tm1, nlr, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(T->act["hr"], hr_t, nhr, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(T->act["pp"], pp_target, nhr, hipMemcpyHostToDevice, st));
+    const float* host_in[9] = {nullptr, nullptr, next_est, nullptr, nullptr, next_hat_est, bic_past, bic_pres, bic_fut};
+    for (int i = 0; i < 9; ++i)
+        if (host_in[i]) HIPCHK(c, hipMemcpyAsync(d->in9[i], host_in[i], nhr, hipMemcpyHostToDevice, st));
+    const float* feat[4];
+    for (int k = 0; k < 4; ++k) {
+        if (!d_targets[k]) return fail(c, SR_ERR_ARG, "feature-map target %d is NULL", k);
+        HIPCHK(c, hipMemcpyAsync(d->featT[k], d_targets[k], (size_t)B * (d->H >> (k + 1)) * (d->W >> (k + 1)) * DISC_COUT[k] * 4, hipMemcpyHostToDevice, st));
+        feat[k] = d->featT[k];
+    }
+    // generator forward (taped)
+    Tape t{c, T, B, c->prec, st};
+    t.hr_warp_out = c->d_hr_warp;
+    if ((rc = train_forward(t, 1, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
+    if ((rc = train_forward(t, 2, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
+    const float* est = c->d_est[1];
+    // discriminator on the generated triplet: forward, losses, backward down to its 27 input channels
+    const sr::Ptr9 p9 = {{c->d_est[0], est, d->in9[2], c->d_hr_warp, est, d->in9[5], d->in9[6], d->in9[7], d->in9[8]}};
+    if ((rc = disc_forward(d, B, p9, true, false))) return fail(c, rc, "%s", d->err.c_str());
+    LAUNCHCHK(c, "bce", launch_bce(d->logit, nullptr, 1.f, B, lw[1], d->prob, d->dlogit, d->d_loss, st));   // target D_ones (TecoGAN.py:473)
+    if ((rc = disc_backward(d, B, feat, lw + 2, true, true))) return fail(c, rc, "%s", d->err.c_str());
+    // generator backward from the weighted losses on its output + what came back through the discriminator
+    const long npix = (long)B * 16 * H * W;
+    // (the discriminator's reduction workspace is sized for its 64-channel HR tensor: 16x what this needs)
+    LAUNCHCHK(c, "teco_est_grad", launch_teco_est_grad(est, T->act["hr"], T->act["pp"], d->gS, t.a("s_out"), t.a("g_est"), d->red,
+                                                       d->d_loss + 5, d->d_loss + 6, npix, lw[0], lw[10], st));
+    t.ext_g_est = true;
+    t.g27 = d->gS;
+    if ((rc = train_backward(t, c->d_lr_t, c->d_lr_tm1, c->d_est[0], T->act["hr"], est, c->d_lr_warp, c->d_flow))) return rc;
+    float dl[8] = {0}, gl[2] = {0};
+    HIPCHK(c, hipMemcpyAsync(dl, d->d_loss, sizeof dl, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(gl, T->d_loss, sizeof gl, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (losses) {   // Keras order: total, then the twelve outputs' unweighted losses (TecoGAN.py:105-108)
+        const float parts[12] = {dl[5], dl[0], dl[1], dl[2], dl[3], dl[4], 0.f, 0.f, 0.f, 0.f, dl[6], gl[1]};
+        double total = 0.0;
+        for (int i = 0; i < 12; ++i) {
+            losses[1 + i] = parts[i];
+            if (i < 6 || i > 9) total += (double)lw[i] * parts[i];
+        }
+        losses[0] = (float)total;
+    }
+    return SR_OK;
+}
+
+// The optimizer step of tecogan.train_on_batch: Adam (Keras 2.2.4) with iteration `t` (the reference's ONE shared Adam,
+// TecoGAN.py:111: the caller keeps its counter) on the generator -- moments of tecogan's own train function, not those of
+// the generator pre-training -- and, when train_disc != 0, on the discriminator too: the reference compiles tecogan while
+// the discriminator is still trainable (TecoGAN.py:122 precedes :461), so its weights are among tecogan's collected
+// trainable weights and move with the combined loss.
+int sr_tecogan_apply(sr_ctx* c, sr_disc* d, float lr, float beta1, float beta2, float eps, int64_t t, int train_disc) {
+    if (!c || !d) return fail(c, SR_ERR_ARG, "NULL argument");
+    if (!c->train) return fail(c, SR_ERR_STATE, "no gradients: call sr_tecogan_grads first");
+    if (t < 1) return fail(c, SR_ERR_ARG, "Adam iteration must be >= 1");
+    HIPCHK(c, hipSetDevice(c->device));
+    sr_train_state* T = c->train;
+    const size_t nb = (size_t)T->nparams * 4;
+    if (!T->d_m2) {
+        HIPCHK(c, hipMalloc((void**)&T->d_m2, nb));
+        HIPCHK(c, hipMalloc((void**)&T->d_v2, nb));
+        HIPCHK(c, hipMemsetAsync(T->d_m2, 0, nb, c->stream));
+        HIPCHK(c, hipMemsetAsync(T->d_v2, 0, nb, c->stream));
+    }
+    const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)t)) / (1.0 - std::pow((double)beta1, (double)t));
+    LAUNCHCHK(c, "adam", launch_adam(T->d_params, T->d_m2, T->d_v2, T->d_grad, T->nparams, (float)lr_t, beta1, beta2, eps, 1.f, c->stream));
+    T->host_stale = true;
+    int rc = repack_all(c);
+    if (rc) return rc;
+    if (train_disc) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(d->stream));
+        if ((rc = disc_apply(d, nullptr, 1.f, lr, beta1, beta2, eps, t, 1, false))) return fail(c, rc, "%s", d->err.c_str());
+    }
     return SR_OK;
 }
 

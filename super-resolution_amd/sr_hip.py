@@ -70,6 +70,21 @@ SIGNATURES = {
     "sr_op_maxpool2_bwd": (C.c_int, [C.c_int] * 5 + [_vp] * 3),
     "sr_op_resize_bilinear_bwd": (C.c_int, [C.c_int] * 6 + [_vp] * 2),
     "sr_op_warp_bwd_flow": (C.c_int, [C.c_int] * 5 + [_vp] * 4),
+    "sr_disc_last_error": (C.c_char_p, [_vp]),
+    "sr_disc_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sr_disc_destroy": (C.c_int, [_vp]),
+    "sr_disc_sync": (C.c_int, [_vp]),
+    "sr_disc_tensor_count": (C.c_int, []),
+    "sr_disc_param_count": (C.c_int, [_vp, _i64p]),
+    "sr_disc_set_tensor": (C.c_int, [_vp, C.c_int, _vp, _i64p, C.c_int]),
+    "sr_disc_commit": (C.c_int, [_vp]),
+    "sr_disc_get_tensor": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, _vp, _i64p, C.POINTER(C.c_int)]),
+    "sr_disc_predict": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _vp, C.POINTER(_vp)]),
+    "sr_disc_train_grads": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _vp, _f32p]),
+    "sr_disc_read_grads": (C.c_int, [_vp, _vp, C.c_int]),
+    "sr_disc_apply": (C.c_int, [_vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_int, C.c_int]),
+    "sr_tecogan_grads": (C.c_int, [_vp, _vp, C.c_int] + [_vp] * 9 + [C.POINTER(_vp), _vp, _f32p, _f32p]),
+    "sr_tecogan_apply": (C.c_int, [_vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_int]),
     "sr_op_conv3x3_wgrad_noalloc": (C.c_int, [C.c_int] * 7 + [_vp] * 5),
     "sr_bench_conv": (C.c_int, [C.c_int] * 10 + [C.POINTER(C.c_float)]),
 }
@@ -341,6 +356,153 @@ class Context:
             out.append(dict(name=name.value.decode(), ms_total=ms.value, launches=n.value,
                             flops_per_launch=fl.value, bytes_per_launch=by.value))
         return out
+
+
+def _ptr_array(arrays):
+    arr = (_vp * len(arrays))()
+    for i, a in enumerate(arrays):
+        arr[i] = a.ctypes.data if a is not None else None
+    return arr
+
+
+class Discriminator:
+    """TecoGAN's spatio-temporal discriminator (reference layers.py:142-186) for HR images of (H, W, 3) on one GPU."""
+
+    FEAT_CH = (64, 64, 128, 256)
+
+    def __init__(self, H, W, max_batch=1, dtype="fp32", device=0):
+        self.H, self.W, self.max_batch, self.device = int(H), int(W), int(max_batch), int(device)
+        self.dtype = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+        self._h = _vp()
+        rc = lib().sr_disc_create(C.byref(self._h), device, H, W, max_batch, self.dtype)
+        if rc:
+            self._h = None
+            self._raise(rc)
+
+    def _raise(self, rc):
+        msg = lib().sr_disc_last_error(self._h).decode("utf-8", "replace")
+        raise (ValueError if rc in (-1, -2, -3) else RuntimeError)(msg)
+
+    def _check(self, rc):
+        if rc:
+            self._raise(rc)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sr_disc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(lib().sr_disc_sync(self._h))
+
+    def feat_shapes(self, B):
+        return [(B, self.H >> (k + 1), self.W >> (k + 1), c) for k, c in enumerate(self.FEAT_CH)]
+
+    def load_weights(self, tensors):
+        """tensors: ordered mapping / iterable of (keras_name, array), the 28 tensors in file order (matched by position)."""
+        items = list(tensors.items() if hasattr(tensors, "items") else tensors)
+        if len(items) != lib().sr_disc_tensor_count():
+            raise ValueError(f"the discriminator has 28 weight tensors, got {len(items)}")
+        for i, (_, arr) in enumerate(items):
+            a = _f32(arr)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            self._check(lib().sr_disc_set_tensor(self._h, i, _ptr(a), shape, a.ndim))
+        self._check(lib().sr_disc_commit(self._h))
+
+    def get_weights(self):
+        out = []
+        name = C.create_string_buffer(256)
+        shape = (C.c_int64 * 4)()
+        rank = C.c_int()
+        for i in range(lib().sr_disc_tensor_count()):
+            self._check(lib().sr_disc_get_tensor(self._h, i, name, 256, None, shape, C.byref(rank)))
+            a = np.empty(tuple(shape[: rank.value]), np.float32)
+            self._check(lib().sr_disc_get_tensor(self._h, i, None, 0, _ptr(a), None, None))
+            out.append((name.value.decode(), a))
+        return out
+
+    def param_count(self):
+        n = C.c_int64()
+        self._check(lib().sr_disc_param_count(self._h, C.byref(n)))
+        return n.value
+
+    def _imgs(self, imgs):
+        imgs = [_f32(a) for a in imgs]
+        if len(imgs) != 9:
+            raise ValueError(f"the discriminator takes 9 images, got {len(imgs)}")
+        B = imgs[0].shape[0]
+        for a in imgs:
+            if a.shape != (B, self.H, self.W, 3):
+                raise ValueError(f"expected images of shape {(B, self.H, self.W, 3)}, got {a.shape}")
+        return B, imgs
+
+    def predict(self, imgs):
+        """[prob (B,1), d_1, d_2, d_3, d_4] like discriminator.predict (inference-mode BatchNormalization)."""
+        B, imgs = self._imgs(imgs)
+        prob = np.empty((B, 1), np.float32)
+        feats = [np.empty(s, np.float32) for s in self.feat_shapes(B)]
+        self._check(lib().sr_disc_predict(self._h, B, _ptr_array(imgs), _ptr(prob), _ptr_array(feats)))
+        return [prob] + feats
+
+    def train_grads(self, imgs, labels, read=False):
+        B, imgs = self._imgs(imgs)
+        lab = _f32(np.asarray(labels).reshape(-1))
+        if lab.shape != (B,):
+            raise ValueError(f"expected {B} labels, got {lab.shape}")
+        loss = C.c_float()
+        self._check(lib().sr_disc_train_grads(self._h, B, _ptr_array(imgs), _ptr(lab), C.byref(loss)))
+        return (loss.value, self.read_grads()) if read else loss.value
+
+    def read_grads(self, d_out=None):
+        if d_out is not None:
+            self._check(lib().sr_disc_read_grads(self._h, _vp(d_out), 1))
+            return None
+        g = np.empty(self.param_count(), np.float32)
+        self._check(lib().sr_disc_read_grads(self._h, _ptr(g), 0))
+        return g
+
+    def apply(self, t, d_grads=None, grad_scale=1.0, lr=5e-5, beta_1=0.9, beta_2=0.999, epsilon=1e-7, slot=0, reset_moments=False):
+        self._check(lib().sr_disc_apply(self._h, _vp(d_grads) if d_grads else None, grad_scale, lr, beta_1, beta_2, epsilon, int(t),
+                                        int(slot), int(bool(reset_moments))))
+
+    def split_grads(self, flat):
+        out, o = {}, 0
+        for name, a in self.get_weights():
+            out[name] = np.asarray(flat[o:o + a.size]).reshape(a.shape)
+            o += a.size
+        return out
+
+
+def tecogan_grads(ctx, disc, lr_t, lr_tm1, est_tm1, next_est, next_hat_est, bic_past, bic_pres, bic_fut, hr_t, d_targets, pp_target,
+                  loss_weights):
+    """tecogan.train_on_batch up to the optimizer (include/sr_hip.h sr_tecogan_grads): returns the 13 losses."""
+    B = int(np.shape(lr_t)[0])
+    ls, hs = ctx._shapes(B)
+    a = [ctx._check_in(lr_t, ls, "I_LR_t"), ctx._check_in(lr_tm1, ls, "I_LR_t_1")]
+    names = ["I_est_t_1", "I_hr_fut", "I_hr_warp_fut", "I_bic_t_1", "I_bic_t", "I_bic_t_fut", "hr_t"]
+    a += [ctx._check_in(x, hs, n) for x, n in zip((est_tm1, next_est, next_hat_est, bic_past, bic_pres, bic_fut, hr_t), names)]
+    feats = [_f32(t) for t in d_targets]
+    for t, s in zip(feats, disc.feat_shapes(B)):
+        if t.shape != s:
+            raise ValueError(f"feature-map target: expected {s}, got {t.shape}")
+    pp = ctx._check_in(pp_target, hs, "ping-pong target")
+    lw = _f32(np.asarray(loss_weights, np.float32))
+    if lw.shape != (12,):
+        raise ValueError("loss_weights: expected the 12 weights of tecogan.compile")
+    losses = (C.c_float * 13)()
+    _check(lib().sr_tecogan_grads(ctx._h, disc._h, B, *[_ptr(x) for x in a], _ptr_array(feats), _ptr(pp), lw.ctypes.data_as(_f32p),
+                                  losses), ctx._h)
+    return list(losses)
+
+
+def tecogan_apply(ctx, disc, t, lr=5e-5, beta_1=0.9, beta_2=0.999, epsilon=1e-7, train_disc=True):
+    _check(lib().sr_tecogan_apply(ctx._h, disc._h, lr, beta_1, beta_2, epsilon, int(t), int(bool(train_disc))), ctx._h)
 
 
 # ---------------------------------------------------------------- single ops

@@ -1,0 +1,290 @@
+"""GPU parity of TecoGAN's discriminator and adversarial step (SURVEY.md section 8 f rank 3; reference layers.py:142-186,
+TecoGAN.py:87-131,434-479) through the C ABI against torch autograd over the CPU oracle (oracle/ref_disc.py, float64).
+
+Bars: inference outputs (probability, feature maps) max-abs error <= 1e-4 in fp32 and <= 1e-3 in bf16x3 (the forward bar of
+BASELINE.json); losses to 1e-5 relative (1e-4 in bf16x3); gradients <= 2e-4 of each tensor's max-abs gradient in fp32,
+1e-2 in bf16x3 (LeakyReLU kink flips, see tests/test_gpu_train.py); moving statistics to 1e-6.  Parity is unpinned by the
+reference itself (no Keras / TF here, no recorded outputs), as for every other row."""
+import numpy as np
+import pytest
+
+from oracle import ref_disc as rd
+from oracle import ref_numpy as rn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sh():
+    import sr_hip
+    assert sr_hip.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    return sr_hip
+
+
+def rel_err(got, want):
+    return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+def images(seed, B, H, W, n=9):
+    """n smooth-ish HR images in [0, 1]: a random low-resolution field upsampled plus a little noise."""
+    out = []
+    for i in range(n):
+        base = rn.uniform01(seed * 100 + i, B * (H // 4) * (W // 4) * 3).reshape(B, H // 4, W // 4, 3)
+        img = np.repeat(np.repeat(base, 4, axis=1), 4, axis=2)
+        img = 0.8 * img + 0.2 * rn.uniform01(seed * 100 + 50 + i, B * H * W * 3).reshape(B, H, W, 3)
+        out.append(img.astype(np.float32))
+    return out
+
+
+def check_named(got, want, tol, skip=()):
+    """tol: a number = bound on every tensor's relative error; a pair (median, max) = bounds on the median over the tensors
+    and on the worst one (bf16x3: its own forward, ~4e-5 away from float64, sits on the other side of some LeakyReLU / clip
+    kinks, and on feature maps as small as 2x2..16x16 one flipped element is percents of a tensor's gradient -- measured:
+    most tensors 2e-5, single ones up to 1.1e-1; the fp32 runs of the same kernels show the arithmetic is right)."""
+    errs = []
+    worst = ("", 0.0)
+    for name, g in want.items():
+        if name in skip:
+            continue
+        if np.abs(g).max() < 1e-12:
+            # the bias of a convolution that feeds BatchNormalization: its gradient is exactly 0 in exact arithmetic
+            # (the batch mean takes it out again); float64 leaves ~1e-17, float32 ~1e-9
+            assert np.abs(got[name]).max() <= 1e-6, name
+            continue
+        e = rel_err(got[name], g)
+        errs.append(e)
+        if e > worst[1]:
+            worst = (name, e)
+    if isinstance(tol, tuple):
+        assert np.median(errs) <= tol[0], f"median relative gradient error {np.median(errs):.2e} > {tol[0]}"
+        tol = tol[1]
+    assert worst[1] <= tol, f"gradient of {worst[0]}: relative error {worst[1]:.2e} > {tol}"
+
+
+def moved_by(want, got):
+    """Largest relative change over the named gradients (those that are not identically zero)."""
+    return max(rel_err(got[k], want[k]) for k in want if np.abs(want[k]).max() >= 1e-12)
+
+
+def conditioned(make, grads, seed0, tries=40, amp=3e-6):
+    """First seed whose oracle gradients do not change (<= 2e-4) when the inputs move by +-amp along three random directions:
+    a LeakyReLU / clip / warp kink closer than fp32 resolution is not a parity case (tests/test_gpu_train.py explains; here a
+    4x4 feature map makes ONE flipped element worth 7 % of conv2d_40's kernel gradient).  make(seed) -> list of float arrays
+    (perturbed) + anything else; grads(arrays) -> tuple of dicts."""
+    for seed in range(seed0, seed0 + tries):
+        arrays = make(seed)
+        want = grads(arrays)
+        rng = np.random.default_rng(seed + 7919)
+        stable = True
+        for _ in range(3):
+            noise = [rng.uniform(-amp, amp, a.shape) for a in arrays]
+            stable = stable and all(
+                max(moved_by(w, g) for w, g in zip(want, grads([a.astype(np.float64) + sign * n for a, n in zip(arrays, noise)]))) <= 2e-4
+                for sign in (1.0, -1.0))
+            if not stable:
+                break
+        if stable:
+            return seed, arrays
+    raise AssertionError("no well-conditioned input found")
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16x3", 1e-3)])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 32, 48), (3, 16, 16)])
+def test_predict_matches_the_oracle(sh, B, H, W, dtype, tol):
+    w = rd.make_disc_weights(3, H, W)
+    imgs = images(1, B, H, W)
+    want_p, want_f = rd.disc_predict(w, imgs)
+    d = sh.Discriminator(H, W, max_batch=B, dtype=dtype)
+    d.load_weights(w)
+    assert d.param_count() == sum(a.size for a in w.values())
+    got = d.predict(imgs)
+    assert got[0].shape == (B, 1)
+    assert np.abs(got[0] - want_p).max() <= tol
+    for g, f in zip(got[1:], want_f):
+        assert g.shape == f.shape
+        assert np.abs(g - f).max() <= tol
+    # a smaller batch on the same object, and weights round-trip (save_weights order and names)
+    if B > 1:
+        got1 = d.predict([a[:1] for a in imgs])
+        assert np.abs(got1[0] - want_p[:1]).max() <= tol
+    back = d.get_weights()
+    assert [n for n, _ in back] == list(w.keys())
+    for n, a in back:
+        assert np.array_equal(a, w[n]), n
+    d.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-4), ("bf16x3", (2e-3, 0.1))])
+@pytest.mark.parametrize("B,H,W,label", [(2, 64, 64, 1.0), (4, 32, 32, 0.0), (1, 48, 32, 1.0)])
+def test_discriminator_step_gradients(sh, B, H, W, label, dtype, tol):
+    """discriminator.train_on_batch([...], [ones | zeros, d_1..d_4]) with loss weights [1,0,0,0,0] (TecoGAN.py:436-458)."""
+    w = rd.make_disc_weights(4, H, W)
+    labels = np.full((B, 1), label, np.float32)
+    _, imgs = conditioned(lambda seed: images(seed, B, H, W), lambda a: (rd.disc_loss_and_grads(w, a, labels)[1],), 2)
+    want_l, want_g, want_stats = rd.disc_loss_and_grads(w, imgs, labels)
+    d = sh.Discriminator(H, W, max_batch=B, dtype=dtype)
+    d.load_weights(w)
+    loss, flat = d.train_grads(imgs, labels, read=True)
+    assert np.isclose(loss, want_l, rtol=1e-5 if dtype == "fp32" else 1e-4)
+    got = d.split_grads(flat)
+    check_named(got, want_g, tol)
+    for n in w:
+        if "moving" in n:
+            assert not got[n].any()                           # not trainable: zeros in the flat gradient
+    # BatchNormalization's moving statistics followed the batch (momentum 0.99, variance fed n / (n - (1 + eps)))
+    now = dict(d.get_weights())
+    for n, a in want_stats.items():
+        assert np.abs(now[n] - a).max() <= (1e-6 if dtype == "fp32" else 1e-5), n
+    # deterministic reductions
+    _, flat2 = d.train_grads(imgs, labels, read=True)
+    assert np.array_equal(flat, flat2)
+    d.close()
+
+
+def keras_adam_step(w, g, m, v, t, lr=5e-5, b1=0.9, b2=0.999, eps=1e-7):
+    lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    return w - lr_t * m / (np.sqrt(v) + eps), m, v
+
+
+def test_discriminator_adam_shares_the_iteration_counter(sh):
+    """Keras 2.2.4 Adam with the iteration count handed in (the reference shares ONE Adam between the three models,
+    TecoGAN.py:111-131) and fresh moments on request (discriminator.compile every iteration, TecoGAN.py:436)."""
+    B, H, W = 2, 32, 32
+    w = rd.make_disc_weights(5, H, W)
+    imgs = images(3, B, H, W)
+    labels = np.ones((B, 1), np.float32)
+    d = sh.Discriminator(H, W, max_batch=B, dtype="fp32")
+    d.load_weights(w)
+    ref = {n: a.astype(np.float64) for n, a in w.items()}
+    m = {n: np.zeros_like(a) for n, a in ref.items()}
+    v = {n: np.zeros_like(a) for n, a in ref.items()}
+    for t, reset in ((7, True), (8, False), (11, True)):
+        _, g, stats = rd.disc_loss_and_grads({n: a.astype(np.float32) for n, a in ref.items()}, imgs, labels)
+        d.train_grads(imgs, labels)
+        d.apply(t, lr=5e-5, slot=0, reset_moments=reset)
+        for n in g:
+            if reset:
+                m[n][:], v[n][:] = 0, 0
+            ref[n], m[n], v[n] = keras_adam_step(ref[n], g[n], m[n], v[n], t)
+        for n, a in stats.items():
+            ref[n] = a.astype(np.float64)
+    got = dict(d.get_weights())
+    for n, a in ref.items():
+        if n.endswith("bias:0") and n.startswith("conv2d") and not n.startswith("conv2d_37"):
+            # gradient identically 0 up to rounding (BatchNormalization follows): Adam turns rounding noise into full-size
+            # steps of random sign, in Keras as here -- nothing to compare
+            continue
+        moved = np.abs(a - w[n]).max()
+        assert moved > 0, n
+        dd = np.abs(got[n] - a)
+        assert dd.mean() <= 0.02 * moved and dd.max() <= 1.0 * moved + 1e-7, (n, dd.mean(), dd.max(), moved)
+    # the forward now runs on the re-packed updated weights
+    want_p, want_f = rd.disc_predict(got, imgs)
+    out = d.predict(imgs)
+    assert np.abs(out[0] - want_p).max() <= 1e-4
+    assert np.abs(out[4] - want_f[3]).max() <= 1e-4
+    d.close()
+
+
+def gan_data(seed, B, h, w):
+    rng = np.random.default_rng(seed)
+    H, W = 4 * h, 4 * w
+    lr_t = rng.random((B, h, w, 3), dtype=np.float32)
+    lr_tm1 = np.clip(lr_t + 0.1 * rng.standard_normal((B, h, w, 3)).astype(np.float32), 0, 1)
+    hr = [rng.random((B, H, W, 3), dtype=np.float32) for _ in range(7)]      # est_tm1, next_est, next_hat, bic x 3, hr_t
+    feats = [rng.standard_normal((B, H >> (k + 1), W >> (k + 1), c)).astype(np.float32) for k, c in enumerate((64, 64, 128, 256))]
+    pp = hr[6][::-1].copy()
+    return [lr_t, lr_tm1] + hr, feats, pp
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-4), ("bf16x3", (5e-3, 0.2))])
+@pytest.mark.parametrize("B,h,w", [(2, 16, 16), (1, 8, 24)])
+def test_tecogan_step_gradients(sh, weights7, B, h, w, dtype, tol):
+    """tecogan.train_on_batch up to the optimizer: 12 losses (VGG weights 0), generator AND discriminator gradients."""
+    H, W = 4 * h, 4 * w
+    dw = rd.make_disc_weights(6, H, W)
+    extra = {}
+
+    def make(seed):
+        ins, extra["feats"], extra["pp"] = gan_data(seed, B, h, w)
+        return ins
+
+    _, ins = conditioned(make, lambda a: rd.tecogan_loss_and_grads(weights7, dw, *a, extra["feats"], extra["pp"])[1:], 703, amp=1e-6)
+    feats, pp = extra["feats"], extra["pp"]
+    want_l, want_gg, want_dg = rd.tecogan_loss_and_grads(weights7, dw, *ins, feats, pp)
+    ctx = sh.Context(h, w, max_batch=B, dtype=dtype, model="tecogan")
+    ctx.load_weights(weights7)
+    d = sh.Discriminator(H, W, max_batch=B, dtype=dtype)
+    d.load_weights(dw)
+    before = dict(d.get_weights())
+    losses = sh.tecogan_grads(ctx, d, *ins, feats, pp, rd.LOSS_WEIGHTS)
+    rtol = 1e-5 if dtype == "fp32" else 2e-4
+    assert np.allclose(losses, want_l, rtol=rtol, atol=1e-7), (losses, want_l)
+    import ctypes as C
+    flat = np.empty(ctx.param_count(), np.float32)
+    assert sh.lib().sr_train_read_grads(ctx._h, flat.ctypes.data_as(C.c_void_p)) == 0
+    got_g = ctx.split_grads(flat)
+    check_named(got_g, want_gg, tol)
+    got_d = d.split_grads(d.read_grads())
+    check_named(got_d, want_dg, tol)
+    # the combined step leaves the moving statistics alone: tecogan's train function is built after
+    # discriminator.trainable = False (TecoGAN.py:461,479), and a non-trainable Keras 2.2.4 layer hands out no updates
+    after = dict(d.get_weights())
+    assert not [n for n in before if not np.array_equal(before[n], after[n])]
+    ctx.close()
+    d.close()
+
+
+def test_tecogan_apply_moves_generator_and_discriminator(sh, weights7):
+    B, h, w = 2, 16, 16
+    H, W = 4 * h, 4 * w
+    dw = rd.make_disc_weights(6, H, W)
+    ins, feats, pp = gan_data(701, B, h, w)
+    _, gg, dg = rd.tecogan_loss_and_grads(weights7, dw, *ins, feats, pp)
+    ctx = sh.Context(h, w, max_batch=B, dtype="fp32", model="tecogan")
+    ctx.load_weights(weights7)
+    d = sh.Discriminator(H, W, max_batch=B, dtype="fp32")
+    d.load_weights(dw)
+    sh.tecogan_grads(ctx, d, *ins, feats, pp, rd.LOSS_WEIGHTS)
+    sh.tecogan_apply(ctx, d, t=5, lr=5e-5, train_disc=True)
+    t = 5
+    step = 5e-5 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+    for got, w0, grads in ((dict(ctx.get_weights()), weights7, gg), (dict(d.get_weights()), dw, dg)):
+        for n, g in grads.items():
+            want, _, _ = keras_adam_step(w0[n].astype(np.float64), g, 0 * g, 0 * g, t)
+            m = np.abs(g) > 1e-2 * np.abs(g).max()
+            if not m.any():
+                continue
+            assert np.abs(got[n] - want)[m].max() <= 0.05 * step * (0.1 / np.sqrt(0.001)) + 1e-7, n
+            assert np.abs(got[n] - w0[n]).max() > 0, n
+    # train_disc = False leaves the discriminator where it is
+    d2 = sh.Discriminator(H, W, max_batch=B, dtype="fp32")
+    d2.load_weights(dw)
+    sh.tecogan_grads(ctx, d2, *ins, feats, pp, rd.LOSS_WEIGHTS)
+    sh.tecogan_apply(ctx, d2, t=6, lr=5e-5, train_disc=False)
+    for n, a in d2.get_weights():
+        if "moving" not in n:
+            assert np.array_equal(a, dw[n]), n
+    for x in (ctx, d, d2):
+        x.close()
+
+
+def test_rejections(sh):
+    with pytest.raises(ValueError):
+        sh.Discriminator(40, 64)                               # not a multiple of 16
+    with pytest.raises(ValueError):
+        sh.Discriminator(64, 64, dtype="bf16")                 # training arithmetic only: fp32 / bf16x3
+    d = sh.Discriminator(32, 32, max_batch=1)
+    with pytest.raises(ValueError):
+        d.predict(images(1, 1, 32, 32))                        # weights not loaded
+    w = rd.make_disc_weights(3, 32, 32)
+    bad = dict(w)
+    bad["dense_1/kernel:0"] = np.zeros((5, 1), np.float32)
+    with pytest.raises(ValueError):
+        d.load_weights(bad)
+    d.load_weights(w)
+    with pytest.raises(ValueError):
+        d.predict(images(1, 2, 32, 32))                        # batch > max_batch
+    d.close()

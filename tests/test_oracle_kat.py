@@ -245,3 +245,68 @@ def test_conv_same_is_zero_padding_one_cross_correlation():
     want = rt.to_nhwc(torch.nn.functional.conv2d(rt.to_nchw(x, torch.float64), torch.tensor(w, dtype=torch.float64).permute(3, 2, 0, 1),
                                                  torch.tensor(b, dtype=torch.float64), padding=1))
     np.testing.assert_allclose(rn.conv3x3_same(x, w, b), want, atol=2e-5)
+
+
+# ------------------------------------------------------------------ discriminator oracle (oracle/ref_disc.py)
+def test_disc_conv4x4_stride2_same_by_definition():
+    """TF SAME at k=4, stride 2 on an even size: out = in / 2, total padding 2 split 1 before / 1 after, cross-correlation:
+    y[i, j, o] = sum_{ky, kx, c} x[2i + ky - 1, 2j + kx - 1, c] * w[ky, kx, c, o] -- spelled out in loops."""
+    from oracle import ref_disc as rd
+    H, W = 16, 16
+    w = rd.make_disc_weights(1, H, W)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, H, W, 27)).astype(np.float32)
+    dw = rd.DiscWeights(w)
+    k0, b0 = w["conv2d_37/kernel:0"].astype(np.float64), w["conv2d_37/bias:0"].astype(np.float64)
+    a0 = rn.conv3x3_same(x.astype(np.float64), k0, b0)
+    a0 = np.where(a0 > 0, a0, 0.2 * a0)
+    k1, b1 = w["conv2d_38/kernel:0"].astype(np.float64), w["conv2d_38/bias:0"].astype(np.float64)
+    z = np.zeros((H // 2, W // 2, 64))
+    xp = np.pad(a0[0], ((1, 1), (1, 1), (0, 0)))
+    for i in range(H // 2):
+        for j in range(W // 2):
+            z[i, j] = np.tensordot(xp[2 * i:2 * i + 4, 2 * j:2 * j + 4], k1, axes=([0, 1, 2], [0, 1, 2])) + b1
+    # inference-mode BatchNormalization with the moving statistics, then LeakyReLU(0.2)
+    g, be, mm, mv = (w[f"batch_normalization_1/{n}:0"].astype(np.float64) for n in ("gamma", "beta", "moving_mean", "moving_variance"))
+    y = (z - mm) / np.sqrt(mv + 1e-3) * g + be
+    y = np.where(y > 0, y, 0.2 * y)
+    _, feats, _, _ = rd.disc_forward(dw, rt.to_nchw(x, torch.float64), training=False)
+    np.testing.assert_allclose(rt.to_nhwc(feats[0])[0], y, atol=1e-10)
+
+
+def test_disc_keras_bce_clips_probabilities():
+    from oracle import ref_disc as rd
+    p = torch.tensor([0.0, 1.0, 0.5, 0.25], dtype=torch.float64)
+    t = torch.tensor([1.0, 0.0, 1.0, 0.0], dtype=torch.float64)
+    want = np.mean([-np.log(1e-7), -np.log(1e-7), -np.log(0.5), -np.log(0.75)])     # 1 - (1 - 1e-7) = 1e-7
+    assert abs(float(rd.keras_bce(p, t)) - want) <= 1e-6
+
+
+def test_disc_training_mode_statistics():
+    """Training mode normalises with the biased batch variance and feeds the moving variance var * n / (n - (1 + eps))."""
+    from oracle import ref_disc as rd
+    B, H, W = 2, 16, 16
+    w = rd.make_disc_weights(2, H, W)
+    rng = np.random.default_rng(1)
+    imgs = [rng.random((B, H, W, 3)).astype(np.float32) for _ in range(9)]
+    dw = rd.DiscWeights(w)
+    _, feats, _, stats = rd.disc_forward(dw, rd.concat9(imgs), training=True)
+    g, be = (w[f"batch_normalization_4/{n}:0"].astype(np.float64) for n in ("gamma", "beta"))
+    y = rt.to_nhwc(feats[3]).astype(np.float64)
+    zn = (np.where(y > 0, y, y / 0.2) - be) / g                 # undo LeakyReLU and the affine part
+    assert np.abs(zn.mean(axis=(0, 1, 2))).max() <= 1e-9
+    n = B * (H // 16) * (W // 16)
+    mean, var_fed = stats[3]
+    z_var = (zn.var(axis=(0, 1, 2)))                            # = var / (var + eps)
+    var = z_var * 1e-3 / (1 - z_var)
+    np.testing.assert_allclose(var_fed.numpy(), var * n / (n - (1 + 1e-3)), rtol=1e-6)
+    _, _, new = rd.disc_loss_and_grads(w, imgs, np.ones((B, 1)))
+    np.testing.assert_allclose(new["batch_normalization_4/moving_mean:0"],
+                               0.99 * w["batch_normalization_4/moving_mean:0"] + 0.01 * mean.numpy(), rtol=1e-6, atol=1e-9)
+
+
+def test_disc_weight_specs_count():
+    from oracle import ref_disc as rd
+    specs = rd.disc_weight_specs(128, 128)
+    assert len(specs) == 28
+    assert sum(int(np.prod(s)) for _, s in specs) == 27 * 9 * 64 + 64 + 16 * (64 * 64 * 2 + 64 * 128 + 128 * 256) + (64 + 64 + 128 + 256) * 5 + 8 * 8 * 256 + 1
