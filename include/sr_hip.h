@@ -277,7 +277,9 @@ int sr_disc_apply(sr_disc* d, const float* d_grads, float grad_scale, float lr, 
  * count as 0), pp_target (the batch-flipped hr_t), lr_t]; loss_weights: the 12 of TecoGAN.py:127-130 (the warp weight must
  * be 1); losses[13] = total + the 12 unweighted parts in Keras' order.  BatchNormalization runs in training mode (learning
  * phase 1) without touching the moving statistics.  Generator gradient -> the ctx (sr_train_read_grads), discriminator
- * gradient -> the discriminator (sr_disc_read_grads).  sr_tecogan_apply: Adam step `t` on the generator (moments of tecogan's
+ * gradient -> the discriminator (sr_disc_read_grads); sr_tecogan_read_grads_dev copies both to DEVICE buffers (NULL skips
+ * one), the all-reduce buffers of a data-parallel job.  sr_tecogan_apply: Adam step `t` from d_gen_grads / d_disc_grads *
+ * grad_scale (DEVICE; NULL = own gradient, unscaled) on the generator (moments of tecogan's
  * own train function) and, with train_disc != 0, on the discriminator: the reference compiles tecogan before it ever sets
  * discriminator.trainable = False (TecoGAN.py:122 vs :461), so Keras 2.2.4 keeps the discriminator's weights among
  * tecogan's collected trainable weights. */
@@ -285,7 +287,9 @@ int sr_tecogan_grads(sr_ctx* ctx, sr_disc* d, int B, const float* lr_t, const fl
                      const float* next_est, const float* next_hat_est, const float* bic_past, const float* bic_pres,
                      const float* bic_fut, const float* hr_t, const float* const* d_targets, const float* pp_target,
                      const float* loss_weights, float* losses);
-int sr_tecogan_apply(sr_ctx* ctx, sr_disc* d, float lr, float beta1, float beta2, float eps, int64_t t, int train_disc);
+int sr_tecogan_apply(sr_ctx* ctx, sr_disc* d, const float* d_gen_grads, const float* d_disc_grads, float grad_scale, float lr,
+                     float beta1, float beta2, float eps, int64_t t, int train_disc);
+int sr_tecogan_read_grads_dev(sr_ctx* ctx, sr_disc* d, float* d_gen_out, float* d_disc_out);
 
 /* The ONE entry point that allocates nothing.  It has no counterpart in the reference; it exists for callers
  * that cannot call hipMalloc: code under HIP graph capture, tight training loops, harnesses that forbid

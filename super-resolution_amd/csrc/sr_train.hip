@@ -934,7 +934,8 @@ int sr_tecogan_grads(sr_ctx* c, sr_disc* d, int B, const float* lr_t, const floa
 // the generator pre-training -- and, when train_disc != 0, on the discriminator too: the reference compiles tecogan while
 // the discriminator is still trainable (TecoGAN.py:122 precedes :461), so its weights are among tecogan's collected
 // trainable weights and move with the combined loss.
-int sr_tecogan_apply(sr_ctx* c, sr_disc* d, float lr, float beta1, float beta2, float eps, int64_t t, int train_disc) {
+int sr_tecogan_apply(sr_ctx* c, sr_disc* d, const float* d_gen_grads, const float* d_disc_grads, float grad_scale, float lr,
+                     float beta1, float beta2, float eps, int64_t t, int train_disc) {
     if (!c || !d) return fail(c, SR_ERR_ARG, "NULL argument");
     if (!c->train) return fail(c, SR_ERR_STATE, "no gradients: call sr_tecogan_grads first");
     if (t < 1) return fail(c, SR_ERR_ARG, "Adam iteration must be >= 1");
@@ -948,15 +949,28 @@ int sr_tecogan_apply(sr_ctx* c, sr_disc* d, float lr, float beta1, float beta2, 
         HIPCHK(c, hipMemsetAsync(T->d_v2, 0, nb, c->stream));
     }
     const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)t)) / (1.0 - std::pow((double)beta1, (double)t));
-    LAUNCHCHK(c, "adam", launch_adam(T->d_params, T->d_m2, T->d_v2, T->d_grad, T->nparams, (float)lr_t, beta1, beta2, eps, 1.f, c->stream));
+    LAUNCHCHK(c, "adam", launch_adam(T->d_params, T->d_m2, T->d_v2, d_gen_grads ? d_gen_grads : T->d_grad, T->nparams, (float)lr_t, beta1,
+                                     beta2, eps, d_gen_grads ? grad_scale : 1.f, c->stream));
     T->host_stale = true;
     int rc = repack_all(c);
     if (rc) return rc;
     if (train_disc) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipStreamSynchronize(d->stream));
-        if ((rc = disc_apply(d, nullptr, 1.f, lr, beta1, beta2, eps, t, 1, false))) return fail(c, rc, "%s", d->err.c_str());
+        if ((rc = disc_apply(d, d_disc_grads, d_disc_grads ? grad_scale : 1.f, lr, beta1, beta2, eps, t, 1, false)))
+            return fail(c, rc, "%s", d->err.c_str());
     }
+    return SR_OK;
+}
+
+// Both gradients of the last sr_tecogan_grads into DEVICE buffers (the all-reduce buffers of a data-parallel job).
+int sr_tecogan_read_grads_dev(sr_ctx* c, sr_disc* d, float* d_gen_out, float* d_disc_out) {
+    if (!c || !d) return fail(c, SR_ERR_ARG, "NULL argument");
+    if (!c->train) return fail(c, SR_ERR_STATE, "no gradients: call sr_tecogan_grads first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (d_gen_out) HIPCHK(c, hipMemcpyAsync(d_gen_out, c->train->d_grad, (size_t)c->train->nparams * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (d_disc_out) HIPCHK(c, hipMemcpyAsync(d_disc_out, d->d_grad, (size_t)d->nparams * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return SR_OK;
 }
 

@@ -61,10 +61,10 @@ def broadcast_weights_(tensors, device):
 class GradBuffer:
     """The flat gradient vector as a torch tensor on the rank's GPU (allocated once)."""
 
-    def __init__(self, n, device):
+    def __init__(self, n, device, n_losses=3):
         import torch
         self.t = torch.empty(int(n), dtype=torch.float32, device=f'cuda:{device}')
-        self.losses = torch.empty(3, dtype=torch.float32, device=f'cuda:{device}')
+        self.losses = torch.empty(int(n_losses), dtype=torch.float32, device=f'cuda:{device}')
 
     def ptr(self):
         return self.t.data_ptr()

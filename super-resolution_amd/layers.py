@@ -305,6 +305,10 @@ class Adam(object):
             raise NotImplementedError('Adam decay / amsgrad are not used by the reference and not built')
         self.lr, self.beta_1, self.beta_2 = float(lr), float(beta_1), float(beta_2)
         self.epsilon = 1e-7 if epsilon is None else float(epsilon)      # K.epsilon()
+        # optimizer.iterations: ONE counter per Adam instance, shared by every model compiled with it (the reference
+        # compiles generator, discriminator and tecogan with the same instance, TecoGAN.py:111-131); the moments belong
+        # to each model's own train function
+        self.iterations = 0
 
 
 class GeneratorModel(_CoreModel):
@@ -358,6 +362,7 @@ class GeneratorModel(_CoreModel):
         else:
             losses = ctx.train_grads(lr_t, lr_tm1, est_tm1, hr_t)
             ctx.train_apply(lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon)
+        opt.iterations += 1
         self.core._dirty = True
         return losses
 
@@ -382,6 +387,7 @@ class GeneratorModel(_CoreModel):
         else:
             losses = ctx.train_clips_grads(hr_clips)
             ctx.train_apply(lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon)
+        opt.iterations += 1
         self.core._dirty = True
         return losses
 
@@ -411,3 +417,230 @@ class HRWarpingModel(_CoreModel):
     def predict(self, x, batch_size=None, verbose=0):
         lr_t, lr_tm1, est_tm1 = _as_list(x)
         return self.core.ctx(len(lr_t)).hr_warp(lr_t, lr_tm1, est_tm1)
+
+
+# ---- TecoGAN's discriminator and combined model (reference layers.py:142-186, TecoGAN.py:87-131) ------------------
+DISC_BLOCKS = [(64, 64), (64, 64), (64, 128), (128, 256)]           # Discriminator_Block filters, layers.py:170-173
+DISC_LOSSES = ['binary_crossentropy'] + ['mean_squared_error'] * 4   # TecoGAN.py:116-119
+
+
+def disc_weight_specs(hr_shape, first_conv=37):
+    """[(keras_name, shape)] of the 28 tensors in Discriminator.save_weights order.  Numbering as in a process that built
+    the generator first (FNet conv2d_1..14, SRNet conv2d_15..36), like reference TecoGAN.py:24-60; Keras matches by ORDER."""
+    H, W, c = (int(v) for v in hr_shape)
+    specs = [(f"conv2d_{first_conv}/kernel:0", (3, 3, 9 * c, 64)), (f"conv2d_{first_conv}/bias:0", (64,))]
+    for k, (cin, cout) in enumerate(DISC_BLOCKS):
+        specs += [(f"conv2d_{first_conv + 1 + k}/kernel:0", (4, 4, cin, cout)), (f"conv2d_{first_conv + 1 + k}/bias:0", (cout,))]
+        specs += [(f"batch_normalization_{k + 1}/{n}:0", (cout,)) for n in ("gamma", "beta", "moving_mean", "moving_variance")]
+    specs += [("dense_1/kernel:0", ((H // 16) * (W // 16) * 256, 1)), ("dense_1/bias:0", (1,))]
+    return specs
+
+
+class DiscriminatorModel(_Model):
+    """9 HR images -> [probability (B,1), d_1..d_4] (reference layers.py:178-183).  predict runs BatchNormalization on the
+    moving statistics, train_on_batch on the batch statistics (and moves the moving ones), like Keras."""
+    name = "Discriminator"
+
+    def __init__(self, hr_shape, dtype="fp32", device=0, seed=None):
+        H, W, c = (int(v) for v in hr_shape)
+        if c != 3:
+            raise ValueError(f"the discriminator expects 3-channel images, got {c}")
+        if H % 16 or W % 16:
+            raise ValueError("Discriminator: HR height and width must be multiples of 16 (four stride-2 convolutions)")
+        self.hr_shape, self.dtype, self.device = (H, W, c), dtype, device
+        rng = np.random.default_rng(seed)
+        self.tensors = []
+        for name, shape in disc_weight_specs(self.hr_shape):
+            if name.endswith("kernel:0"):                       # glorot_uniform, the Keras default of Conv2D and Dense
+                fan_in = int(np.prod(shape[:-1]))
+                fan_out = int(np.prod(shape[:2])) * shape[3] if len(shape) == 4 else shape[1]
+                limit = np.sqrt(6.0 / (fan_in + fan_out))
+                a = rng.uniform(-limit, limit, size=shape)
+            elif name.endswith("gamma:0") or name.endswith("moving_variance:0"):
+                a = np.ones(shape)
+            else:
+                a = np.zeros(shape)
+            self.tensors.append((name, a.astype(np.float32)))
+        self.trainable = True
+        self.optimizer = None
+        self._fresh_moments = True
+        self._native = None
+        self._native_batch = 0
+        self._dirty = False
+        self._gbuf = None
+
+    # -- weights
+    def refresh(self):
+        if self._dirty and self._native is not None:
+            self.tensors = self._native.get_weights()
+        self._dirty = False
+
+    def named_weights(self):
+        self.refresh()
+        return list(self.tensors)
+
+    def get_weights(self):
+        return [a for _, a in self.named_weights()]
+
+    def set_weights(self, weights):
+        weights = list(weights)
+        if len(weights) != len(self.tensors):
+            raise ValueError(f"{self.name}: expected {len(self.tensors)} arrays, got {len(weights)}")
+        new = []
+        for (n, cur), a in zip(self.tensors, weights):
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if a.shape != cur.shape:
+                raise ValueError(f"{n}: shape {a.shape} does not match {cur.shape}")
+            new.append((n, a))
+        self.tensors, self._dirty = new, False
+        if self._native is not None:
+            self._native.load_weights(self.tensors)
+
+    def load_weights(self, path):
+        """Keras matches the file's weighted layers to the model's BY ORDER: the layer numbering of the saving process
+        (conv2d_37 here, anything elsewhere) does not matter."""
+        tensors = weights_io.read_tensors(path)
+        if len(tensors) != len(self.tensors):
+            raise ValueError(f"{path}: holds {len(tensors)} tensors, the model {self.name} expects {len(self.tensors)}")
+        self.set_weights([a for _, a in tensors])
+
+    def save_weights(self, path):
+        weights_io.write_tensors(path, self.named_weights(), keep_layer_prefix=True)
+
+    # -- native object (lazy, sized by the largest batch seen)
+    def native(self, batch):
+        if self._native is None or batch > self._native_batch:
+            if self._native is not None:
+                print('[WARN] the discriminator batch grew: the native object is rebuilt, weights are kept, Adam moments restart')
+                self.refresh()
+                self._native.close()
+            H, W, _ = self.hr_shape
+            self._native = sr_hip.Discriminator(H, W, max_batch=int(batch), dtype=self.dtype, device=self.device)
+            self._native_batch = int(batch)
+            self._native.load_weights(self.tensors)
+        return self._native
+
+    def predict(self, x, batch_size=None, verbose=0):
+        imgs = _as_list(x)
+        return self.native(len(imgs[0])).predict(imgs)
+
+    def compile(self, loss, loss_weights=None, optimizer=None):
+        """What the reference compiles (TecoGAN.py:116-120, 436-440): binary cross-entropy on the probability, the four
+        feature maps with weight 0.  Every compile gives the train function fresh Adam moments (the reference re-compiles
+        each iteration); the iteration counter lives in the shared optimizer."""
+        weights = [1., 0., 0., 0., 0.] if loss_weights is None else [float(v) for v in loss_weights]
+        if list(loss) != DISC_LOSSES or weights != [1., 0., 0., 0., 0.]:
+            raise NotImplementedError("the native discriminator step implements loss=['binary_crossentropy', 4 x "
+                                      "'mean_squared_error'] with loss_weights=[1, 0, 0, 0, 0] (reference TecoGAN.py:116-120)")
+        self.optimizer = optimizer if optimizer is not None else Adam()
+        self._fresh_moments = True
+
+    def train_on_batch(self, x, y):
+        """[9 images], [labels, d_1..d_4] -> [total, bce, 0, 0, 0, 0]: the feature-map targets carry weight 0 and are not
+        evaluated (Keras would report their mean squared errors; the reference discards the return value, TecoGAN.py:450)."""
+        if self.optimizer is None:
+            raise RuntimeError('You must compile a model before training/testing. Use `model.compile(optimizer, loss)`.')
+        imgs = _as_list(x)
+        labels = np.asarray(_as_list(y)[0], np.float32).reshape(-1)
+        d = self.native(len(imgs[0]))
+        opt = self.optimizer
+        opt.iterations += 1
+        kw = dict(lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon, slot=0, reset_moments=self._fresh_moments)
+        import dp
+        if dp.world()[1] > 1:
+            dp.init_if_needed()
+            if self._gbuf is None:
+                self._gbuf = dp.GradBuffer(d.param_count(), self.device)
+            loss = d.train_grads(imgs, labels)
+            d.read_grads(d_out=self._gbuf.ptr())
+            loss = self._gbuf.reduce([loss, 0.0, 0.0])[0]
+            d.apply(opt.iterations, d_grads=self._gbuf.ptr(), **kw)
+        else:
+            loss = d.train_grads(imgs, labels)
+            d.apply(opt.iterations, **kw)
+        self._fresh_moments = False
+        self._dirty = True
+        return [loss, loss, 0.0, 0.0, 0.0, 0.0]
+
+
+class Discriminator(object):
+    def __init__(self, HR_shape, dtype="fp32", device=0):
+        self.HR_shape = HR_shape
+        self.dtype, self.device = dtype, device
+
+    def build(self):
+        return DiscriminatorModel(self.HR_shape, dtype=self.dtype, device=self.device)
+
+
+# loss_weights of tecogan.compile (TecoGAN.py:127-130): GT, Dst, Ds1..Ds4, VGG22/34/44/54, ping-pong, warp
+TECOGAN_LOSS_WEIGHTS = [1., -1e-3, 1.67e-3, 1.43e-3, 8.33e-4, 2e-5, 3e-5, 1.4e-6, 6e-6, 2e-3, 0.25, 1.]
+
+
+class TecoGANModel(_Model):
+    """tecogan: [I_LR_t, I_LR_t_1, I_est_t_1, I_hr_fut, I_hr_warp_fut, I_bic_t_1, I_bic_t, I_bic_t_fut] -> the 12 outputs of
+    reference TecoGAN.py:101-108; only train_on_batch is built (the reference never predicts with it).  The four VGG19
+    terms need ImageNet weights (keras.applications downloads them): their weights are taken as 0 and their losses
+    reported as 0.  train_discriminator: the reference compiles tecogan while the discriminator is trainable
+    (TecoGAN.py:122 before :461), so Keras 2.2.4 moves the discriminator's weights in this step too -- the default here;
+    False freezes them, which is what the reference's author presumably intended."""
+    name = "model_1"
+
+    def __init__(self, gen, disc, train_discriminator=True):
+        self.gen, self.disc = gen, disc
+        self.train_discriminator = bool(train_discriminator)
+        self.optimizer = None
+        self.loss_weights = list(TECOGAN_LOSS_WEIGHTS)
+        self._gbuf = None
+
+    def named_weights(self):
+        return self.gen.named_weights() + self.disc.named_weights()
+
+    def get_weights(self):
+        return [a for _, a in self.named_weights()]
+
+    def compile(self, loss, loss_weights=None, optimizer=None):
+        loss = list(loss)
+        if len(loss) != 12 or [loss[i] for i in (0, 1, 2, 3, 4, 5, 10, 11)] != ['mean_squared_error', 'binary_crossentropy'] + ['mean_squared_error'] * 6:
+            raise NotImplementedError('tecogan.compile: the native step implements the 12 losses of reference TecoGAN.py:122-126')
+        lw = list(TECOGAN_LOSS_WEIGHTS) if loss_weights is None else [float(v) for v in loss_weights]
+        if len(lw) != 12 or lw[11] != 1.0:
+            raise NotImplementedError('tecogan.compile: 12 loss weights, the warp weight must be 1 (reference TecoGAN.py:127-130)')
+        self.loss_weights = lw
+        self.optimizer = optimizer if optimizer is not None else Adam()
+
+    def train_on_batch(self, x, y):
+        """-> [total, GT, Dst, Ds1..Ds4, 0, 0, 0, 0, ping-pong, warp] (Keras order).  Targets: y[1] must be ones, y[11] must be
+        I_LR_t (reference TecoGAN.py:473-476); y[6..9] (VGG targets) are ignored."""
+        if self.optimizer is None:
+            raise RuntimeError('You must compile a model before training/testing. Use `model.compile(optimizer, loss)`.')
+        lr_t, lr_tm1, est_tm1, next_est, next_hat_est, bic_past, bic_pres, bic_fut = _as_list(x)
+        y = _as_list(y)
+        if len(y) != 12:
+            raise ValueError(f'tecogan.train_on_batch: expected 12 targets, got {len(y)}')
+        if not np.all(np.asarray(y[1]) == 1):
+            raise NotImplementedError('the adversarial target must be ones (reference TecoGAN.py:473)')
+        if y[11] is not lr_t and not np.array_equal(np.asarray(y[11], np.float32), np.asarray(lr_t, np.float32)):
+            raise NotImplementedError('the last target must be I_LR_t (reference TecoGAN.py:476)')
+        B = len(lr_t)
+        ctx = self.gen.core.ctx(B)
+        d = self.disc.native(B)
+        opt = self.optimizer
+        losses = sr_hip.tecogan_grads(ctx, d, lr_t, lr_tm1, est_tm1, next_est, next_hat_est, bic_past, bic_pres, bic_fut, y[0], y[2:6],
+                                      y[10], self.loss_weights)
+        opt.iterations += 1
+        kw = dict(lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon, train_disc=self.train_discriminator)
+        import dp
+        if dp.world()[1] > 1:
+            dp.init_if_needed()
+            ng, nd = ctx.param_count(), d.param_count()
+            if self._gbuf is None:
+                self._gbuf = dp.GradBuffer(ng + nd, self.gen.core.device, n_losses=13)
+            sr_hip.tecogan_read_grads_dev(ctx, d, self._gbuf.ptr(), self._gbuf.ptr() + 4 * ng)
+            losses = self._gbuf.reduce(losses)
+            sr_hip.tecogan_apply(ctx, d, opt.iterations, d_gen_grads=self._gbuf.ptr(), d_disc_grads=self._gbuf.ptr() + 4 * ng, **kw)
+        else:
+            sr_hip.tecogan_apply(ctx, d, opt.iterations, **kw)
+        self.gen.core._dirty = True
+        if self.train_discriminator:
+            self.disc._dirty = True
+        return losses

@@ -84,7 +84,8 @@ SIGNATURES = {
     "sr_disc_read_grads": (C.c_int, [_vp, _vp, C.c_int]),
     "sr_disc_apply": (C.c_int, [_vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_int, C.c_int]),
     "sr_tecogan_grads": (C.c_int, [_vp, _vp, C.c_int] + [_vp] * 9 + [C.POINTER(_vp), _vp, _f32p, _f32p]),
-    "sr_tecogan_apply": (C.c_int, [_vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_int]),
+    "sr_tecogan_apply": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_int]),
+    "sr_tecogan_read_grads_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
     "sr_op_conv3x3_wgrad_noalloc": (C.c_int, [C.c_int] * 7 + [_vp] * 5),
     "sr_bench_conv": (C.c_int, [C.c_int] * 10 + [C.POINTER(C.c_float)]),
 }
@@ -501,8 +502,15 @@ def tecogan_grads(ctx, disc, lr_t, lr_tm1, est_tm1, next_est, next_hat_est, bic_
     return list(losses)
 
 
-def tecogan_apply(ctx, disc, t, lr=5e-5, beta_1=0.9, beta_2=0.999, epsilon=1e-7, train_disc=True):
-    _check(lib().sr_tecogan_apply(ctx._h, disc._h, lr, beta_1, beta_2, epsilon, int(t), int(bool(train_disc))), ctx._h)
+def tecogan_apply(ctx, disc, t, lr=5e-5, beta_1=0.9, beta_2=0.999, epsilon=1e-7, train_disc=True, d_gen_grads=None, d_disc_grads=None,
+                  grad_scale=1.0):
+    _check(lib().sr_tecogan_apply(ctx._h, disc._h, _vp(d_gen_grads) if d_gen_grads else None, _vp(d_disc_grads) if d_disc_grads else None,
+                                  grad_scale, lr, beta_1, beta_2, epsilon, int(t), int(bool(train_disc))), ctx._h)
+
+
+def tecogan_read_grads_dev(ctx, disc, d_gen_out=None, d_disc_out=None):
+    _check(lib().sr_tecogan_read_grads_dev(ctx._h, disc._h, _vp(d_gen_out) if d_gen_out else None, _vp(d_disc_out) if d_disc_out else None),
+           ctx._h)
 
 
 # ---------------------------------------------------------------- single ops

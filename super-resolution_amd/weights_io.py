@@ -60,10 +60,13 @@ def _local(name):
     return name.split("/", 1)[1] if "/" in name else name
 
 
-def write_tensors(path, tensors, weightless_layers=()):
+def write_tensors(path, tensors, weightless_layers=(), keep_layer_prefix=False):
     """weightless_layers: names of extra top-level layers without weights (Keras lists every layer of the model in
-    ``layer_names`` -- the inputs, Upscaling_0, Warp_1 ... -- each with an empty group)."""
+    ``layer_names`` -- the inputs, Upscaling_0, Warp_1 ... -- each with an empty group).
+    keep_layer_prefix: the model's layers are plain layers, not sub-models (the discriminator): Keras names the weight
+    ``conv2d_37/kernel:0`` and stores it INSIDE the group ``conv2d_37``, i.e. at ``conv2d_37/conv2d_37/kernel:0``."""
     tensors = [(n, np.ascontiguousarray(a, np.float32)) for n, a in tensors]
+    _local = (lambda n: n) if keep_layer_prefix else globals()["_local"]
     ext = os.path.splitext(path)[1].lower()
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     if ext == ".npz":

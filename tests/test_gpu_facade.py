@@ -128,9 +128,11 @@ def test_train_stage_runs_the_reference_loop(tmp_path, weights7):
 
 
 def test_tecogan_generator_pretraining_stage(tmp_path, weights7):
-    """TecoGAN.train(): the generator pre-training phase (reference TecoGAN.py:164-275) runs natively with
-    the halving learning-rate schedule and writes generator checkpoints; the adversarial phase says it is not built."""
+    """TecoGAN.train(): the generator pre-training phase (reference TecoGAN.py:164-275) runs natively with the halving
+    learning-rate schedule and writes generator checkpoints; the adversarial phase then starts at iteration 0 and 5e-5."""
     from oracle import ref_train
+    from TecoGAN import TecoGAN
+    assert [TecoGAN.gen_learning_rate(i) for i in (0, 49999, 50000, 100000, 10 ** 7)] == [1e-4, 1e-4, 5e-5, 2.5e-5, 2.5e-5]
     t = build('tecogan', (16, 16, 3), tmp_path, weights7)
     os.makedirs(tmp_path / 'clips')
     np.save(tmp_path / 'clips' / '0.npy', (rn.synth_clip(31, 6, 80, 80, scale=4) * 255).astype(np.uint8))
@@ -138,10 +140,23 @@ def test_tecogan_generator_pretraining_stage(tmp_path, weights7):
                           'info_freq': 1, 'seed': 3, 'pretrained_disc': None}
     t.configs['data'].update(high_res=64)
     assert t.generator.optimizer.lr == 5e-5                                   # TecoGAN.py:110
+    assert t.generator.optimizer is t.discriminator.optimizer is t.tecogan.optimizer   # ONE Adam, TecoGAN.py:111-131
     before = [a.copy() for a in weights7.values()]                            # train() loads cnn.pretrained_model first
-    with pytest.raises(NotImplementedError, match='adversarial'):
-        t.train()                                                            # iterations 0, 1 (< iterations / 2)
-    assert t.generator.optimizer.lr == 1e-4                                   # schedule value at i < 50k
+
+    class EndOfPretraining(Exception):
+        pass
+
+    seen = {}
+
+    def stop(hr):
+        seen['lr'], seen['shape'] = t.generator.optimizer.lr, hr.shape
+        raise EndOfPretraining()
+
+    t.gan_iteration = stop
+    with pytest.raises(EndOfPretraining):
+        t.train()                                                            # iterations 0, 1 (< iterations / 2), then the GAN loop
+    assert seen == {'lr': 5e-5, 'shape': (1, 3, 64, 64, 3)}                   # TecoGAN.py:278
+    assert t.opt.iterations == 2                                              # the shared counter saw the two generator steps
     assert (tmp_path / 'Checkpoints' / 'generator_model_weights_1.h5').exists() and (tmp_path / 'TecoGAN.yaml').exists()
     after = t.generator.get_weights()
     moved = max(np.abs(a - b).max() for a, b in zip(after, before))
@@ -154,3 +169,73 @@ def test_tecogan_generator_pretraining_stage(tmp_path, weights7):
     want_l, _, _ = ref_train.loss_and_grads(w_now, x[0], x[1], x[2], y[0], model='tecogan')
     loss = t.generator.train_on_batch(x, y)
     assert np.allclose(loss, want_l, rtol=1e-4)
+
+
+def test_tecogan_adversarial_stage(tmp_path, weights7):
+    """The adversarial phase (reference TecoGAN.py:277-527): the ping-pong batch against the oracle's recurrence and warps,
+    one whole iteration (2 discriminator steps with fresh moments, predict, 2 combined steps, one shared Adam counter)
+    against the oracle's restatement, then train() itself with a pretrained discriminator: checkpoints of both models."""
+    from oracle import ref_disc as rd
+    import utils
+    import weights_io
+    t = build('tecogan', (16, 16, 3), tmp_path, weights7)
+    t._load_pretrained()
+    dw = rd.make_disc_weights(9, 64, 64)
+    t.discriminator.set_weights(list(dw.values()))
+    assert [n for n, _ in t.discriminator.named_weights()] == list(dw.keys())
+    hr = rn.synth_clip(41, 4, 64, 64, scale=4)[None]                          # one clip of c = 4 frames
+    b = t.make_gan_batch(hr)
+    assert all(a.shape[0] == 4 for a in b.values()) and len(b) == 16          # 2 groups x (c - 2) frames
+    assert np.array_equal(b['hr'], b['hr'][::-1])                             # ping-pong: the batch is its own mirror image
+    assert np.array_equal(b['hr'][0], hr[0, 1]) and np.array_equal(b['next_hr'][1], hr[0, 3]) and np.array_equal(b['prev_hr'][2], hr[0, 3])
+    lr = utils.blur_cubic_downscale(hr[0])
+    assert np.abs(b['lr'][1] - lr[2]).max() <= 2e-6 and np.abs(b['next_lr'][3] - lr[0]).max() <= 2e-6
+    assert np.abs(b['bic'][0] - utils.cubic_upscale4(b['lr'][0:1])[0]).max() <= 1e-6
+    fwd = rt.run_clip(weights7, lr[:, None], model='tecogan')                # forward group through the oracle
+    bwd = rt.run_clip(weights7, lr[::-1][:, None], model='tecogan')          # the reversed group
+    assert np.abs(b['est'][0] - fwd[1, 0]).max() <= 1e-3 and np.abs(b['prev_est'][1] - fwd[1, 0]).max() <= 1e-3
+    assert np.abs(b['est'][2] - bwd[1, 0]).max() <= 1e-3 and np.abs(b['next_est'][3] - bwd[3, 0]).max() <= 1e-3
+    taps = {}
+    rt.generator_step(weights7, b['lr'][1:2], b['next_lr'][1:2], b['next_est'][1:2], model='tecogan', taps=taps)
+    assert np.abs(b['next_hat_est'][1] - taps['hr_warp'][0]).max() <= 2e-4
+    rt.generator_step(weights7, b['lr'][2:3], b['prev_lr'][2:3], b['prev_hr'][2:3], model='tecogan', taps=taps)
+    assert np.abs(b['prev_hat_hr'][2] - taps['hr_warp'][0]).max() <= 2e-4
+    # one iteration against the oracle, from the same batch arrays
+    t.make_gan_batch = lambda _hr: b
+    moments = ({}, {}, {}, {})
+    gen_w, disc_w, its, want_l = rd.gan_iteration(dict(weights7), dict(dw), b, 0, moments)
+    loss = t.gan_iteration(hr)
+    assert t.opt.iterations == its == 4
+    assert np.allclose(loss, want_l, rtol=2e-3, atol=1e-6), (loss, want_l)
+    step = 5e-5 * 4
+    got_g = dict(zip(weights7.keys(), t.generator.get_weights()))
+    got_d = dict(t.discriminator.named_weights())
+    for got, want, w0 in ((got_g, gen_w, weights7), (got_d, disc_w, dw)):
+        for n, a in want.items():
+            if n.startswith('conv2d_') and n.endswith('bias:0') and not n.startswith('conv2d_37'):
+                continue                                                      # zero gradient (BatchNormalization follows): Adam steps on rounding noise
+            d = np.abs(got[n] - a)
+            if 'moving' in n:
+                assert d.max() <= 1e-5, n
+                continue
+            assert np.abs(a - w0[n]).max() > 0, n
+            assert d.mean() <= 0.05 * step and d.max() <= 2.01 * step, (n, d.mean(), d.max())
+    # the stage: pretrained discriminator => no pre-training (TecoGAN.py:148-152), 2 iterations, both checkpoints
+    del t.make_gan_batch
+    os.makedirs(tmp_path / 'clips')
+    np.save(tmp_path / 'clips' / '0.npy', (rn.synth_clip(31, 6, 80, 80, scale=4) * 255).astype(np.uint8))
+    weights_io.write_tensors(str(tmp_path / 'd.h5'), list(dw.items()), keep_layer_prefix=True)
+    t.configs['train'] = {'iterations': 2, 'batch_size': 2, 'c_frames': 4, 'sample_freq': 1, 'checkpoint_freq': 1,
+                          'info_freq': 1, 'seed': 3, 'pretrained_disc': 'd.h5'}
+    t.configs['data'].update(high_res=64)
+    loss = t.train()
+    assert len(loss) == 13 and all(np.isfinite(loss)) and loss[7:11] == [0.0] * 4     # the VGG terms count as 0
+    assert t.opt.iterations == 4 + 2 * 4
+    ck = tmp_path / 'Checkpoints'
+    assert (ck / 'generator_model_weights_1.h5').exists() and (ck / 'discriminator_model_weights_1.h5').exists()
+    assert t.configs['train']['pretrained_disc'].endswith('discriminator_model_weights_1.h5')
+    saved = weights_io.read_tensors(str(ck / 'discriminator_model_weights_1.h5'))
+    assert [n for n, _ in saved] == list(dw.keys())
+    for (n, a), (_, cur) in zip(saved, t.discriminator.named_weights()):
+        np.testing.assert_array_equal(a, cur)
+    assert (tmp_path / 'Samples' / 'Sample_1.npy').exists()

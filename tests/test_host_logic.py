@@ -281,10 +281,69 @@ def test_out_of_scope_stages_say_so():
     m = FrameRecurrentVideoSR((16, 16, 3), (64, 64, 3), '/tmp/o', CFG)
     with pytest.raises(NotImplementedError):
         m.run()
-    t = TecoGAN((16, 16, 3), (64, 64, 3), '/tmp/o', dict(CFG, train={'iterations': 0, 'pretrained_disc': 'd.h5'}))
-    with pytest.raises(NotImplementedError):
-        t.train()                                                    # adversarial phase: a later row
+    t = TecoGAN((16, 16, 3), (64, 64, 3), '/tmp/o', dict(CFG))
+    with pytest.raises(NotImplementedError, match='ImageNet'):
+        t.vgg_54(None, None)                                         # perceptual losses: the weights are a download
     assert [TecoGAN.gen_learning_rate(i) for i in (0, 49999, 50000, 100000, 10 ** 6)] == [1e-4, 1e-4, 5e-5, 2.5e-5, 2.5e-5]
+
+
+def test_discriminator_model_weights_and_files(tmp_path):
+    """layers.Discriminator(HR_shape).build() (reference layers.py:142-186): 28 tensors in Keras order, fresh-model
+    initialisation, save_weights in the Keras layout of a model made of plain layers (dataset conv2d_37/conv2d_37/kernel:0),
+    load_weights by ORDER whatever the saving process numbered its layers."""
+    import layers
+    import weights_io
+    d = layers.Discriminator((64, 48, 3)).build()
+    assert d.name == 'Discriminator' and d.trainable is True
+    named = d.named_weights()
+    assert len(named) == 28 and d.count_params() == sum(int(np.prod(s)) for _, s in layers.disc_weight_specs((64, 48, 3)))
+    shapes = dict((n, a.shape) for n, a in named)
+    assert shapes['conv2d_37/kernel:0'] == (3, 3, 27, 64) and shapes['conv2d_41/kernel:0'] == (4, 4, 128, 256)
+    assert shapes['dense_1/kernel:0'] == (4 * 3 * 256, 1) and shapes['batch_normalization_4/moving_variance:0'] == (256,)
+    w = dict(named)
+    assert np.all(w['batch_normalization_2/gamma:0'] == 1) and np.all(w['batch_normalization_2/moving_variance:0'] == 1)
+    assert not w['batch_normalization_2/beta:0'].any() and not w['conv2d_38/bias:0'].any() and w['conv2d_38/kernel:0'].std() > 0
+    d.save_weights(str(tmp_path / 'd.h5'))
+    back = weights_io.read_tensors(str(tmp_path / 'd.h5'))
+    assert [n for n, _ in back] == [n for n, _ in named]
+    import h5lite
+    with h5lite.File(str(tmp_path / 'd.h5'), 'r') as f:
+        assert [x.decode() for x in f['conv2d_37'].attrs['weight_names']] == ['conv2d_37/kernel:0', 'conv2d_37/bias:0']
+        assert f['conv2d_37']['conv2d_37/kernel:0'][()].shape == (3, 3, 27, 64)
+    # a file written by a process that numbered its layers differently loads by position
+    other = [(n.replace('conv2d_3', 'conv2d_').replace('conv2d_4', 'conv2d_1'), a + 1) for n, a in named]
+    weights_io.write_tensors(str(tmp_path / 'e.npz'), other)
+    d.load_weights(str(tmp_path / 'e.npz'))
+    for a, (_, b) in zip(d.get_weights(), named):
+        np.testing.assert_array_equal(a, b + 1)
+    with pytest.raises(ValueError):
+        d.set_weights(d.get_weights()[:-1])
+    with pytest.raises(ValueError):
+        layers.Discriminator((40, 64, 3)).build()                      # four stride-2 convolutions: multiples of 16
+    opt = layers.Adam(lr=5e-5)
+    with pytest.raises(NotImplementedError):
+        d.compile(loss=['binary_crossentropy'] + ['mean_squared_error'] * 4, loss_weights=[1., 1., 0., 0., 0.], optimizer=opt)
+    with pytest.raises(RuntimeError):
+        d.train_on_batch([None] * 9, [None] * 5)                       # not compiled
+    d.compile(loss=['binary_crossentropy'] + ['mean_squared_error'] * 4, loss_weights=[1., 0., 0., 0., 0.], optimizer=opt)
+    assert d.optimizer is opt and opt.iterations == 0 and d._fresh_moments
+
+
+def test_tecogan_model_compile_contract():
+    import layers
+    core = layers.GeneratorCore((16, 16, 3), model='tecogan')
+    gen, disc = layers.GeneratorModel(core, 'Generator'), layers.Discriminator((64, 64, 3)).build()
+    m = layers.TecoGANModel(gen, disc)
+    assert len(m.get_weights()) == 76 + 28 and m.train_discriminator
+    losses = ['mean_squared_error', 'binary_crossentropy'] + ['mean_squared_error'] * 4 + [print] * 4 + ['mean_squared_error'] * 2
+    with pytest.raises(RuntimeError):
+        m.train_on_batch([None] * 8, [None] * 12)
+    with pytest.raises(NotImplementedError):
+        m.compile(loss=losses, loss_weights=[1.] * 11 + [0.5])
+    with pytest.raises(NotImplementedError):
+        m.compile(loss=['mean_squared_error'] * 12)
+    m.compile(loss=losses, loss_weights=layers.TECOGAN_LOSS_WEIGHTS, optimizer=layers.Adam(lr=5e-5))
+    assert m.loss_weights[1] == -1e-3 and m.loss_weights[10] == 0.25
 
 
 def test_clip_loader_rejects_videos(tmp_path):
