@@ -136,8 +136,10 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
         unsigned off0;      // offset of the halo origin of plane 0 (wraps for row -1 / column -1: only in-image units use it)
         unsigned okm;       // bit i: this lane's unit of DMA instruction i lies inside the image
         unsigned eoff[2];   // epilogue: offset of this lane's record of (M block, first plane of this half), or `dump`
-        unsigned estep;     // + this for the second plane (0 for dump lanes)
     };
+    // + one plane for the second plane of the half; a lane whose pixel lies outside the image stays in the dump area (M
+    // block 1 of a tile that straddles the right edge is outside for lanes whose M block 0 pixel is inside)
+    auto estep = [&](unsigned eoff) { return eoff != dump ? plane_bytes : 0u; };
     auto locate = [&](int tt) {
         Tile q;
         const int b = tt / per_img;
@@ -159,7 +161,6 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
             const bool ok = y < H && x < W;
             q.eoff[mb] = ok ? row + (unsigned)x * 64u : dump;
         }
-        q.estep = (y < H && x0 + 1 + r < W) ? plane_bytes : 0u;   // lane r of block 1 is inside only if lane r of block 0 is
         return q;
     };
     // addresses are a.in + 32-bit offset: SGPR base + one VGPR per DMA
@@ -233,7 +234,6 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
     f32x16 acc[2], fin[2];      // running tile; finished tile whose epilogue is being drained
     Tile done;                  // where `fin` goes
     done.eoff[0] = done.eoff[1] = dump;
-    done.estep = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) fin[0][i] = fin[1][i] = 0.f;
 
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
             __builtin_amdgcn_s_barrier();           // every wave's part landed; every wave is done reading the other buffer
             asm volatile("" ::: "memory");
             Piece pc;
-            ep_load(pc, done.eoff[mbp] + (plp ? done.estep : 0u));     // before the DMA: older in the vmcnt queue
+            ep_load(pc, done.eoff[mbp] + (plp ? estep(done.eoff[mbp]) : 0u));     // before the DMA: older in the vmcnt queue
             if (C < 3) issue(cur, C + 1, (q + 1) & 1);
             else issue(nxt, 0, (q + 1) & 1);        // past the last tile: re-reads this tile's first plane, harmless
             const unsigned char* at = abuf + (q & 1) * TK::A_BYTES;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
             Piece pc;
-            ep_load(pc, done.eoff[mb] + (pl ? done.estep : 0u));
+            ep_load(pc, done.eoff[mb] + (pl ? estep(done.eoff[mb]) : 0u));
             ep_wait(pc, std::integral_constant<int, 0>{});
 #pragma unroll
             for (int k = 0; k < 4; ++k) ep_pair(pc, fin[mb][8 * pl + 2 * k], fin[mb][8 * pl + 2 * k + 1], k);
