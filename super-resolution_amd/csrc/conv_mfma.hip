@@ -9,14 +9,18 @@
 //   pixel's 32*STEPS payload bytes followed by 16 B of padding so the 32 lanes of
 //   an A-fragment read (ds_read_b128, one pixel per lane) fall on 16 distinct
 //   16-B bank slots.  Weights are pre-packed on the host in exactly the per-lane
-//   B-fragment order and stream from L2 with one coalesced 1-KiB
-//   global_load_dwordx4 per (tap, k-step, N block) per wave, through a register
-//   ring that runs PF k-steps ahead of the MFMAs (the stream is contiguous over
-//   passes, chunks, taps and steps, so the ring never drains inside a tile).
+//   B-fragment order.  Three kernels share the geometry:
+//     conv3x3_lds_kernel   (the hot one: FNet, the heads, every stride-1 layer of the training step) keeps the
+//                          chunk's packed weights in LDS next to the halo tile, copied once per workgroup and chunk;
+//     convT3x3_lds_kernel  copies ONE tap's weights per barrier into one of two LDS buffers;
+//     conv3x3_kernel       (layers whose channels do not fit those: the fallback) streams the weights from L2 with one
+//                          coalesced 1-KiB global_load_dwordx4 per (tap, k-step, N block) per wave through a register
+//                          ring that runs PF k-steps ahead of the MFMAs.
 //   The next chunk's halo tile is fetched into registers while the current
 //   chunk computes.  The weights are the MFMA's A operand and the pixels its B
 //   operand: D then has the pixel on the lane (lane & 31) and 4 consecutive output
 //   channels per register quad, so the epilogue stores 16 B per lane.
+//   (The SRNet trunk's 64 -> 64 layers at inference run on conv_trunk.hip, not here.)
 //
 //   M_CONV : 8-row tiles, one pass over 9 taps, chunks of 32*STEPS payload bytes.
 //   M_CONVT: out[2i+ky, 2j+kx] += in[i,j] w[ky,kx]  =>  four output phases
