@@ -587,8 +587,47 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[G::MT][NT], con
             }
         }
     }
-    // 2. row reads (same wave: LDS ops of one wave execute in order), residual add, coalesced stores
     const int iy0 = y0 + G::MT * wave + 2 * mg;
+    if (a.pool_out) {
+        // 2'. max pooling 2x2 / 2 straight from the scratch: the two tile rows of this round are one pooled row; pooled
+        // pixel j takes scratch rows 2j, 2j+1 (upper) and 32+2j, 33+2j (lower).  H, W even: a window is inside or outside whole.
+        const int Hp = H >> 1, Wp = W >> 1;
+        unsigned char* pp = reinterpret_cast<unsigned char*>(a.pool_out) + (size_t)b * Hp * Wp * a.out_cs * SZ + cob;
+        const int iyp = iy0 >> 1;
+#pragma unroll
+        for (int k = 0; k < (E::NIT + 3) / 4; ++k) {
+            const int pj = prow + k * E::RPI;                    // 0..15
+            const int ixp = (x0 >> 1) + pj;
+            if (pj < 16) {
+                const unsigned char* s0 = sc + (2 * pj) * E::ROW + chunk * 16;
+                u32x4 v[4] = {*reinterpret_cast<const u32x4*>(s0), *reinterpret_cast<const u32x4*>(s0 + E::ROW),
+                              *reinterpret_cast<const u32x4*>(s0 + 32 * E::ROW), *reinterpret_cast<const u32x4*>(s0 + 33 * E::ROW)};
+                u32x4 o;
+                if constexpr (SZ == 4) {
+                    f32x4 m = __builtin_bit_cast(f32x4, v[0]);
+#pragma unroll
+                    for (int q = 1; q < 4; ++q) {
+                        const f32x4 t = __builtin_bit_cast(f32x4, v[q]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], t[j]);
+                    }
+                    o = __builtin_bit_cast(u32x4, m);
+                } else {
+                    bf16x8 m = __builtin_bit_cast(bf16x8, v[0]);
+#pragma unroll
+                    for (int q = 1; q < 4; ++q) {
+                        const bf16x8 t = __builtin_bit_cast(bf16x8, v[q]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) m[j] = (float)t[j] > (float)m[j] ? t[j] : m[j];
+                    }
+                    o = __builtin_bit_cast(u32x4, m);
+                }
+                if (cok && iyp < Hp && ixp < Wp) *reinterpret_cast<u32x4*>(pp + ((size_t)iyp * Wp + ixp) * a.out_cs * SZ) = o;
+            }
+        }
+        continue;
+    }
+    // 2. row reads (same wave: LDS ops of one wave execute in order), residual add, coalesced stores
     const int p0 = prow;                                     // pixel of iteration 0; iteration k adds k*RPI
     const bool colok = cok;
 #pragma unroll
@@ -969,7 +1008,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a) {
                 __syncthreads();   // the tile's last chunk has been read by every wave: LDS becomes scratch
                 { unsigned long long tb = SR_T(); ts[4] += tb - t2; }
                 const bool interior = cur.y0 + G::TH <= H && cur.x0 + TW <= W &&
-                                      (int)(blockIdx.y + 1) * NT * 32 <= a.cout_store && a.act != A_CLIP01;
+                                      (int)(blockIdx.y + 1) * NT * 32 <= a.cout_store && a.act != A_CLIP01 && !a.pool_out;
                 if (interior) {
                     if (a.out_f32) epilogue_lds_fast<G, NT, float, MASK>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem, es, stamp);
                     else epilogue_lds_fast<G, NT, __bf16, MASK>(acc, a, cur.b, cur.y0, cur.x0, wave, lane, smem, es, stamp);

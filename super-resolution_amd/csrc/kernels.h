@@ -47,6 +47,10 @@ struct ConvArgs {
     // that produced this conv's gradient target; out = conv(in) * act'(y) (1 where y > 0, else 0 / 0.2),
     // no bias activation of its own.  M_CONV, fp32 / bf16x3, vector-aligned strides only.
     int res_mask;
+    // M_CONV on the LDS-transpose path: instead of the activated output, store its 2x2 / stride-2 max pooling
+    // [B,H/2,W/2,out_cs] here (H, W even; `out` is not written).  FNet's encoder: Conv2D + LeakyReLU + MaxPooling2D,
+    // reference layers.py:31-36 -- the full-resolution tensor has no other reader.
+    void* pool_out;
 };
 
 // steps per chunk / chunk geometry, shared by the packer and the kernel

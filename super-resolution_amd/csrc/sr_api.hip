@@ -312,6 +312,10 @@ int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, con
     a.proj_w = io.proj_w;
     a.res_mask = io.res_mask;
     a.in_split = io.in_split;
+    a.pool_out = io.pool_out;
+    if (io.pool_out && (L.tapsn || L.mode != M_CONV || io.res || io.out_planar || io.res_mask || (io.H & 1) || (io.W & 1) ||
+                        (io.cout_store * (io.out_f32 ? 4 : 2)) % 16 || (io.out_cs * (io.out_f32 ? 4 : 2)) % 16))
+        return fail(c, SR_ERR_ARG, "%s: the fused max pooling needs a plain 3x3 conv on an even-sized image with vector-aligned channels", name);
     if (io.in_split) {
         if (L.mode != M_CONVT || prec != P_BF16X3 || !io.in_planar || !L.d_w2 || L.nchunk != 1 || L.steps != 4)
             return fail(c, SR_ERR_ARG, "%s: a split-planar input needs the bf16x3 64-channel transposed conv with its second packing", name);
@@ -423,10 +427,16 @@ int run_fnet(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, float
         int rc = run_conv(c, P, st, c->fnet[k++], B, {x, lv[l].H, lv[l].W, b(A[l]), ch[l], ch[l], af, nullptr, 0, A_LRELU}, nm);
         if (rc) return rc;
         snprintf(nm, sizeof nm, "fnet.conv%d", k + 1);
-        rc = run_conv(c, P, st, c->fnet[k++], B, {b(A[l]), lv[l].H, lv[l].W, b(Bb[l]), ch[l], ch[l], af, nullptr, 0, A_LRELU}, nm);
+        ConvIO io2 = {b(A[l]), lv[l].H, lv[l].W, b(Bb[l]), ch[l], ch[l], af, nullptr, 0, A_LRELU};
+        // MaxPooling2D in the producing conv's epilogue (the unpooled tensor has no other reader); SR_NO_FUSE_POOL=1: separate kernel
+        const bool fuse_pool = l < 3 && c->fuse_pool;
+        if (fuse_pool) io2.pool_out = b(Pn[l + 1]);
+        rc = run_conv(c, P, st, c->fnet[k++], B, io2, nm);
         if (rc) return rc;
         x = b(Bb[l]);
-        if (l < 3) {
+        if (fuse_pool) {
+            x = b(Pn[l + 1]);
+        } else if (l < 3) {
             snprintf(nm, sizeof nm, "fnet.pool%d", l + 1);
             const double bytes = (double)B * lv[l].H * lv[l].W * ch[l] * (bf ? 2 : 4) * 1.25;
             ProfScope ps(c, nm, 0, bytes);
@@ -701,6 +711,7 @@ static int create_common(sr_ctx** out, int device, int h_in, int w_in, int ch, i
     c->model = model;
     if (const char* e = getenv("SR_TRUNK_SUB")) c->trunk_sub = atoi(e);
     if (getenv("SR_NO_PLANAR")) c->planar_trunk = 0;
+    c->fuse_pool = getenv("SR_NO_FUSE_POOL") ? 0 : 1;
     if (const char* e = getenv("SR_SPLIT_TRUNK")) c->split_trunk = atoi(e);
     int rc = SR_OK;
     auto bail = [&](int code) {

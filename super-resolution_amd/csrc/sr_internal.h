@@ -96,6 +96,7 @@ struct sr_ctx {
     // 65,536 pixels (small steps are launch bound: the resident-weight kernel reloads 72 KiB per workgroup per launch),
     // 2 = always (SR_SPLIT_TRUNK=2, tests), 0 = never (SR_SPLIT_TRUNK=0)
     int split_trunk = 1;
+    int fuse_pool = 1;                   // FNet: MaxPooling2D in the producing conv's epilogue (SR_NO_FUSE_POOL=1: separate kernel)
     bool step_split = false;   // the step being enqueued uses it
     // two lanes: a step's batch is split into halves that run on `stream` and on `stream2` between a
     // fork and a join event, so one half's kernels fill the partial last round of workgroups (and the
@@ -182,6 +183,7 @@ struct ConvIO {
     const void* proj_w = nullptr;        // transposed conv: fused tap projection, out = P [B,2H,2W,32] fp32
     int in_split = 0;                    // transposed conv, bf16x3: planar input is split-planar; uses the layer's d_w2
     int res_mask = 0;                    // kernels.h ConvArgs::res_mask: res is the activation output to mask by
+    void* pool_out = nullptr;            // kernels.h ConvArgs::pool_out: store the 2x2 max pooling of the output here instead
 };
 
 int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, const ConvIO& io, const char* name);

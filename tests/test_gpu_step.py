@@ -86,10 +86,11 @@ def test_step_vs_oracle_fp32(sh, weights7, h, w, B):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
-@pytest.mark.parametrize("env", ["SR_NO_PLANAR", "SR_NO_FUSE_OUT", "SR_NO_TAPSN"])
+@pytest.mark.parametrize("env", ["SR_NO_PLANAR", "SR_NO_FUSE_OUT", "SR_NO_TAPSN", "SR_NO_FUSE_POOL"])
 def test_layout_switches_keep_parity(sh, weights7, env, dtype):
     """The A/B switches (NHWC trunk instead of 64-byte planes; unfused transposed conv + 64->3 conv;
-    generic kernel for the <=3-channel convs) select older kernels of the same path: same bar."""
+    generic kernel for the <=3-channel convs; FNet's max pooling as a kernel of its own instead of inside the
+    producing conv's epilogue) select older kernels of the same path: same bar."""
     lr_t, lr_tm1, est = step_inputs(300, 2, 24, 40)
     want, want_lw = rt.generator_step(weights7, lr_t, lr_tm1, est)
     os.environ[env] = "1"
@@ -104,6 +105,29 @@ def test_layout_switches_keep_parity(sh, weights7, env, dtype):
         os.environ.pop("SR_NO_FUSE_OUT", None)
     assert np.abs(got - want).max() <= FP32_TOL
     assert np.abs(lw - want_lw).max() <= FP32_TOL
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("B,h,w", [(2, 24, 40), (1, 8, 72), (1, 96, 144)])
+def test_fused_max_pooling_is_the_pooling_kernel(sh, weights7, B, h, w, dtype):
+    """FNet with MaxPooling2D inside the conv epilogue against the same convs followed by the pooling kernel: a maximum of
+    identical numbers, bit for bit (ragged tiles: 72 and 144 columns are not multiples of the 32-column tile, 24 / 96 rows
+    leave partial 8-row tiles at the lower levels)."""
+    lr_t, lr_tm1, _ = step_inputs(310 + h, B, h, w)
+    flows = []
+    for off in (False, True):
+        if off:
+            os.environ["SR_NO_FUSE_POOL"] = "1"
+        try:
+            ctx = make_ctx(sh, weights7, h, w, B, dtype=dtype)
+            flows.append(ctx.fnet(lr_t, lr_tm1))
+            ctx.close()
+        finally:
+            os.environ.pop("SR_NO_FUSE_POOL", None)
+    assert np.array_equal(flows[0], flows[1])
+    if dtype != "bf16":
+        want = rt.to_nhwc(rt.fnet(rt.TorchWeights(weights7), rt.to_nchw(lr_t), rt.to_nchw(lr_tm1)))
+        assert np.abs(flows[0] - want).max() <= FP32_TOL
 
 
 def test_golden_clip24x40(sh, weights7):
