@@ -393,6 +393,12 @@ def main():
         if world == 1:
             out["end_to_end"] = end_to_end(torch, sr_hip, weights, lr[:, :BATCH], args.dtype, local_rank, max(FRAMES, args.steps // 2))
             out["train_step"] = train_step_rate(weights, args.dtype if args.dtype != "bf16" else "bf16x3")
+            # BASELINE.json configs[4] (TecoGAN adversarial step), one GPU: the reference's 64-sample batch at its own 32x32 LR
+            # crops and a smaller batch at the 128x128 LR crops the config names (tools/gan_bench.py)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import gan_bench
+            tdt = args.dtype if args.dtype != "bf16" else "bf16x3"
+            out["tecogan_step"] = [gan_bench.run(64, 32, tdt, 3, local_rank), gan_bench.run(8, 128, tdt, 2, local_rank)]
             out["cpu_baseline"], cpu_frames = cpu_baseline(weights, lr[:, :1])
             err = float(np.abs(gpu_frames - np.stack([f[0] for f in cpu_frames])).max())
             out["verified"] = bool(err <= VERIFY_TOL[args.dtype])

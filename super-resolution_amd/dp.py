@@ -16,10 +16,16 @@ def world():
             int(os.environ.get('LOCAL_RANK', '0')))
 
 
+def active():
+    """Is the data-parallel path on?  WORLD_SIZE > 1, or SR_DP_FORCE=1: a ONE-rank process group, which sends the gradient
+    through the same RCCL all-reduce (the only way to execute that path on a box with a single GPU)."""
+    return world()[1] > 1 or os.environ.get('SR_DP_FORCE') == '1'
+
+
 def init_if_needed(backend=None):
-    """Join the process group when launched with WORLD_SIZE > 1; returns the world size."""
+    """Join the process group when the data-parallel path is on; returns the world size."""
     rank, n, _ = world()
-    if n <= 1:
+    if not active():
         return 1
     import torch.distributed as dist
     if not dist.is_initialized():
@@ -32,7 +38,7 @@ def init_if_needed(backend=None):
 def mean_over_ranks_(tensor):
     """In-place all-reduce(sum) / world size; identity for a single process."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return tensor
     dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
     tensor /= dist.get_world_size()

@@ -352,7 +352,7 @@ class GeneratorModel(_CoreModel):
         ctx = self.core.ctx(len(lr_t))
         opt = self.optimizer
         import dp
-        if dp.world()[1] > 1:
+        if dp.active():
             dp.init_if_needed()
             if getattr(self, '_gbuf', None) is None:
                 self._gbuf = dp.GradBuffer(ctx.param_count(), self.core.device)
@@ -378,7 +378,7 @@ class GeneratorModel(_CoreModel):
         ctx = self.core.ctx(hr_clips.shape[0] * hr_clips.shape[1])
         opt = self.optimizer
         import dp
-        if dp.world()[1] > 1:
+        if dp.active():
             dp.init_if_needed()
             if getattr(self, '_gbuf', None) is None:
                 self._gbuf = dp.GradBuffer(ctx.param_count(), self.core.device)
@@ -547,7 +547,7 @@ class DiscriminatorModel(_Model):
         opt.iterations += 1
         kw = dict(lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon, slot=0, reset_moments=self._fresh_moments)
         import dp
-        if dp.world()[1] > 1:
+        if dp.active():
             dp.init_if_needed()
             if self._gbuf is None:
                 self._gbuf = dp.GradBuffer(d.param_count(), self.device)
@@ -630,7 +630,7 @@ class TecoGANModel(_Model):
         opt.iterations += 1
         kw = dict(lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon, train_disc=self.train_discriminator)
         import dp
-        if dp.world()[1] > 1:
+        if dp.active():
             dp.init_if_needed()
             ng, nd = ctx.param_count(), d.param_count()
             if self._gbuf is None:

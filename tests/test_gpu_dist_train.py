@@ -99,3 +99,91 @@ def test_two_ranks_train_like_one_process_on_the_whole_batch(weights7):
     for k in (2, 4):
         for x, y in zip(got[0][k], got[1][k]):
             np.testing.assert_array_equal(x, y)                                        # the ranks stay in lock step exactly
+
+
+def _rccl_worker(port, out):
+    """ONE rank on backend nccl (= RCCL): the gradient goes through the same all-reduce a multi-GPU job runs."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      SR_DP_FORCE="1", SR_DIST_BACKEND="nccl")
+    for p in (ROOT, os.path.join(ROOT, "super-resolution_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import dp
+    import torch.distributed as dist
+    from layers import Adam, Discriminator, GeneratorCore, GeneratorModel, TecoGANModel
+    from oracle import ref_numpy as rn
+    assert dp.active()
+    core = GeneratorCore((16, 16, 3), model="tecogan", dtype="fp32", device=0)
+    core.set_tensors(list(rn.make_weights(seed=7).items()))
+    m = GeneratorModel(core, "Generator")
+    opt = Adam(lr=1e-4)
+    m.compile(loss=["mean_squared_error"] * 2, loss_weights=[1., 1.], optimizer=opt)
+    a, b, c, hr = _batch(2, 16, 16)
+    losses = m.train_on_batch([a, b, c], [hr, a])
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    w_gen = [x.copy() for x in m.get_weights()]
+    # the adversarial models use the same path: discriminator step and combined step through RCCL
+    d = Discriminator((64, 64, 3), device=0).build()
+    d.set_weights([np.asarray(x) for x in _disc_weights()])
+    d.compile(loss=["binary_crossentropy"] + ["mean_squared_error"] * 4, loss_weights=[1., 0., 0., 0., 0.], optimizer=opt)
+    imgs = _gan_images()
+    dl = d.train_on_batch(imgs, [np.ones(2, np.float32)] + [None] * 4)
+    feats = d.predict(imgs)[1:]
+    g = TecoGANModel(m, d)
+    g.compile(loss=["mean_squared_error", "binary_crossentropy"] + ["mean_squared_error"] * 4 + [None] * 4 + ["mean_squared_error"] * 2,
+              optimizer=opt)
+    gl = g.train_on_batch([a, b, c] + imgs[:5], [hr, np.ones(2, np.float32)] + feats + [hr] * 4 + [hr[::-1].copy(), a])
+    out.put((losses, w_gen, dl, gl, [x.copy() for x in m.get_weights()], [x.copy() for x in d.get_weights()], opt.iterations))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _disc_weights():
+    from oracle import ref_disc as rd
+    return list(rd.make_disc_weights(9, 64, 64).values())
+
+
+def _gan_images():
+    rng = np.random.default_rng(11)
+    return [rng.random((2, 64, 64, 3), dtype=np.float32) for _ in range(9)]
+
+
+def test_one_rank_on_rccl_equals_the_plain_process(weights7):
+    """The data-parallel path executed on RCCL itself (backend nccl, one rank: all this box has): generator step,
+    discriminator step and combined step with the gradient all-reduced through torch.distributed must give the weights of
+    the plain single-process path (a one-rank mean is the identity)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    losses, w_gen, dl, gl, w_gen2, w_disc, its = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    from layers import Adam, Discriminator, GeneratorCore, GeneratorModel, TecoGANModel
+    core = GeneratorCore((16, 16, 3), model="tecogan", dtype="fp32", device=0)
+    core.set_tensors(list(weights7.items()))
+    m = GeneratorModel(core, "Generator")
+    opt = Adam(lr=1e-4)
+    m.compile(loss=["mean_squared_error"] * 2, loss_weights=[1., 1.], optimizer=opt)
+    a, b, c, hr = _batch(2, 16, 16)
+    want_l = m.train_on_batch([a, b, c], [hr, a])
+    assert np.allclose(losses, want_l, rtol=1e-6)
+    for x, y in zip(w_gen, m.get_weights()):
+        np.testing.assert_array_equal(x, y)
+    d = Discriminator((64, 64, 3), device=0).build()
+    d.set_weights(_disc_weights())
+    d.compile(loss=["binary_crossentropy"] + ["mean_squared_error"] * 4, loss_weights=[1., 0., 0., 0., 0.], optimizer=opt)
+    imgs = _gan_images()
+    want_dl = d.train_on_batch(imgs, [np.ones(2, np.float32)] + [None] * 4)
+    feats = d.predict(imgs)[1:]
+    g = TecoGANModel(m, d)
+    g.compile(loss=["mean_squared_error", "binary_crossentropy"] + ["mean_squared_error"] * 4 + [None] * 4 + ["mean_squared_error"] * 2,
+              optimizer=opt)
+    want_gl = g.train_on_batch([a, b, c] + imgs[:5], [hr, np.ones(2, np.float32)] + feats + [hr] * 4 + [hr[::-1].copy(), a])
+    assert np.allclose(dl, want_dl, rtol=1e-6) and np.allclose(gl, want_gl, rtol=1e-5, atol=1e-7)
+    assert its == opt.iterations == 3
+    for x, y in zip(w_gen2, m.get_weights()):
+        np.testing.assert_array_equal(x, y)
+    for x, y in zip(w_disc, d.get_weights()):
+        np.testing.assert_array_equal(x, y)
