@@ -128,12 +128,17 @@ def pmc_traffic(dtype):
             tag = d.get("trunk_kernel", {}).get(dtype) or {
                 "bf16x3": "conv3x3_lds_kernel<2, 2, 1, true>", "bf16": "conv3x3_lds_kernel<1, 2, 2, true>",
                 "fp32": "conv3x3_lds_kernel<0, 2, 2, true>"}[dtype]
-            best = None
-            for k, v in d["kernels"].items():   # the trunk's grid is the one with the most launches
-                if k.startswith(tag) and (best is None or v["launches"] > best["launches"]):
-                    best = v
-            if best:
-                return best["hbm_bytes"], name
+            tags = tag if isinstance(tag, list) else [tag]
+            found = []
+            for t in tags:
+                best = None
+                for k, v in d["kernels"].items():   # the trunk's grid is the one with the most launches
+                    if k.startswith(t) and (best is None or v["launches"] > best["launches"]):
+                        best = v
+                if best:
+                    found.append(best["hbm_bytes"])
+            if len(found) == len(tags):
+                return round(sum(found) / len(found)), name
         except (OSError, KeyError, ValueError):
             continue
     return None, None

@@ -3,6 +3,11 @@
 
     python tools/pmc_summary.py stats   <dir with *_kernel_stats.csv>  > profiles/rN_..._kernel_stats.csv
     python tools/pmc_summary.py traffic <fetch dir> <write dir> <out.json>
+    python tools/pmc_summary.py durations <dir with *kernel_trace.csv>  > profiles/rN_..._launch_durations.csv
+    python tools/pmc_summary.py counters <dir> <counter> [<counter> ...]  (per kernel and grid: mean per launch)
+
+`durations` groups the kernel trace by (kernel, grid size): rocprofv3's own --stats summary groups by name only, which
+mixes e.g. the whole-batch and the sub-batch launches of one kernel.
 
 `traffic` reads two separate --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on
 gfx950: 3 + 2 of the 4 TCC slots) and writes per-kernel HBM bytes per launch.  Corrections follow
@@ -49,6 +54,21 @@ def main():
         files = glob.glob(os.path.join(sys.argv[2], "**", "*kernel_stats.csv"), recursive=True)
         for f in files:
             sys.stdout.write(open(f).read())
+        return
+    if sys.argv[1] == "durations":
+        acc = collections.defaultdict(list)
+        for f in glob.glob(os.path.join(sys.argv[2], "**", "*kernel_trace.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                grid = r.get("Grid_Size") or str(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))
+                acc[short(r["Kernel_Name"]) + " @grid" + grid].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        print("kernel @grid,launches,avg_us,min_us,max_us,total_ms")
+        for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+            print(f'"{k}",{len(v)},{sum(v) / len(v):.2f},{min(v):.2f},{max(v):.2f},{sum(v) / 1e3:.3f}')
+        return
+    if sys.argv[1] == "counters":
+        for ctr in sys.argv[3:]:
+            for k, (v, n) in sorted(per_kernel(sys.argv[2], ctr).items(), key=lambda kv: -kv[1][0] * kv[1][1])[:12]:
+                print(f"{ctr:32s} {k[:90]:90s} launches {n:5d} mean per launch {v:.4g}")
         return
     fetch = per_kernel(sys.argv[2], "FETCH_SIZE")
     write = per_kernel(sys.argv[3], "WRITE_SIZE")
