@@ -290,6 +290,16 @@ int sr_tecogan_grads(sr_ctx* ctx, sr_disc* d, int B, const float* lr_t, const fl
 int sr_tecogan_apply(sr_ctx* ctx, sr_disc* d, const float* d_gen_grads, const float* d_disc_grads, float grad_scale, float lr,
                      float beta1, float beta2, float eps, int64_t t, int train_disc);
 int sr_tecogan_read_grads_dev(sr_ctx* ctx, sr_disc* d, float* d_gen_out, float* d_disc_out);
+/* One whole pass of the adversarial loop body (reference TecoGAN.py:434-479) on one GPU, every host array uploaded once:
+ * arrays[15] = {lr, prev_lr, hr, prev_hr, next_hr, prev_hat_hr, next_hat_hr, est, prev_est, next_est, prev_hat_est,
+ * next_hat_est, bic, prev_bic, next_bic} (the *_batch arrays of TecoGAN.py:416-432; LR (B,h,w,3), the rest (B,4h,4w,3)).
+ * Runs discriminator.train_on_batch on the real triplets (labels 1; fresh Adam moments as after TecoGAN.py:436) and on
+ * the generated ones (labels 0), discriminator.predict on the real triplets (the feature-map targets, kept on the
+ * device), and tecogan.train_on_batch twice with the batch-flipped hr as ping-pong target (TecoGAN.py:469-479).  t0 = the
+ * shared Adam counter before the pass (it advances by 4).  losses[13]: the last combined step; disc_losses[2] (nullable):
+ * the two discriminator losses.  Same arithmetic as the step-by-step entry points (tests/test_gpu_disc.py). */
+int sr_tecogan_iteration(sr_ctx* ctx, sr_disc* d, int B, const float* const* arrays, const float* loss_weights, float lr,
+                         float beta1, float beta2, float eps, int64_t t0, int train_disc, float* losses, float* disc_losses);
 
 /* The ONE entry point that allocates nothing.  It has no counterpart in the reference; it exists for callers
  * that cannot call hipMalloc: code under HIP graph capture, tight training loops, harnesses that forbid

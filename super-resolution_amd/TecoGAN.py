@@ -26,6 +26,7 @@ from utils import cubic_upscale4, denormalize, get_frames, get_videos, load_clip
 
 class TecoGAN(FrameRecurrentVideoSR):
     model_kind = 'tecogan'
+    step_by_step = False      # True: the adversarial pass goes through the five model calls of the reference instead of one native call
 
     def build(self):
         super().build()
@@ -109,6 +110,19 @@ class TecoGAN(FrameRecurrentVideoSR):
         of the real triplets as targets.  Returns the last tecogan.train_on_batch losses."""
         b = self.make_gan_batch(hr_clips)
         k = len(b['hr'])
+        self._last_gan_batch = b
+        if not dp.active() and not self.step_by_step:
+            # one native call: every array goes to the device once, the feature-map targets never leave it
+            # (sr_tecogan_iteration; the calls below are the same pass through the Keras-shaped model objects)
+            opt = self.opt
+            ctx, d = self.core.ctx(k), self.discriminator.native(k)
+            loss, _ = sr_hip.tecogan_iteration(ctx, d, b, self.tecogan.loss_weights, opt.iterations, lr=opt.lr, beta_1=opt.beta_1,
+                                               beta_2=opt.beta_2, epsilon=opt.epsilon, train_disc=self.tecogan.train_discriminator)
+            opt.iterations += 4
+            self.core._dirty = self.discriminator._dirty = True
+            self.discriminator._fresh_moments = False
+            self.discriminator.trainable = False
+            return loss
         ones, zeros = np.ones(k, np.float32), np.zeros(k, np.float32)
         self.discriminator.trainable = True
         self.discriminator.compile(loss=['binary_crossentropy'] + ['mean_squared_error'] * 4,
@@ -125,7 +139,6 @@ class TecoGAN(FrameRecurrentVideoSR):
         loss = None
         for _ in range(2):
             loss = self.tecogan.train_on_batch(net_input, net_output)
-        self._last_gan_batch = b
         return loss
 
     # ------------------------------------------------------------------ training (TecoGAN.py:136-527)

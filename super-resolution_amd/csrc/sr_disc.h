@@ -25,6 +25,7 @@ struct sr_disc {
     float *wg_part = nullptr, *dw3 = nullptr;
     float* in9[9] = {};                    // device copies of the nine input images (host entry points)
     float* featT[4] = {};                  // device copies of feature-map targets
+    std::vector<float*> it_buf;            // sr_tecogan_iteration: the thirteen HR arrays of one pass (allocated on first use)
 };
 
 namespace srh {

@@ -258,6 +258,8 @@ int sr_disc_destroy(sr_disc* d) {
             if (p) (void)hipFree(p);
     for (float* p : d->in9)
         if (p) (void)hipFree(p);
+    for (float* p : d->it_buf)
+        if (p) (void)hipFree(p);
     if (d->red) (void)hipFree(d->red);
     for (int l = 0; l < 5; ++l) {
         free_layer(d->conv[l]);

@@ -845,10 +845,8 @@ int sr_op_warp_bwd_flow(int device, int B, int H, int W, int C, const float* img
 // (the four VGG19 terms need ImageNet weights, a download: they count as 0 and their weights are ignored) and the
 // backward through both networks.  Generator gradient -> the ctx's flat vector (sr_train_read_grads / sr_train_grads'
 // layout), discriminator gradient -> the discriminator's (sr_disc_read_grads).
-int sr_tecogan_grads(sr_ctx* c, sr_disc* d, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1,
-                     const float* next_est, const float* next_hat_est, const float* bic_past, const float* bic_pres,
-                     const float* bic_fut, const float* hr_t, const float* const* d_targets, const float* pp_target,
-                     const float* loss_weights, float* losses) {
+// checks shared by the host-array entry points of the combined step
+static int tecogan_ready(sr_ctx* c, sr_disc* d, int B, const float* loss_weights) {
     int rc = check_ready(c, B);
     if (rc) return rc;
     if (!d) return fail(c, SR_ERR_ARG, "discriminator is NULL");
@@ -857,62 +855,47 @@ int sr_tecogan_grads(sr_ctx* c, sr_disc* d, int B, const float* lr_t, const floa
     if (!d->committed) return fail(c, SR_ERR_WEIGHTS, "the discriminator's weights are not committed");
     if (d->device != c->device || d->H != 4 * c->h || d->W != 4 * c->w || B > d->max_batch)
         return fail(c, SR_ERR_ARG, "discriminator (%dx%d, max batch %d, device %d) does not fit this generator", d->H, d->W, d->max_batch, d->device);
-    if (!lr_t || !lr_tm1 || !est_tm1 || !next_est || !next_hat_est || !bic_past || !bic_pres || !bic_fut || !hr_t || !d_targets ||
-        !pp_target || !loss_weights)
-        return fail(c, SR_ERR_ARG, "NULL tensor pointer");
-    const float* lw = loss_weights;
-    if (lw[11] != 1.f) return fail(c, SR_ERR_ARG, "the warp loss weight must be 1 (reference TecoGAN.py:130); other values are not built");
+    if (!loss_weights) return fail(c, SR_ERR_ARG, "NULL tensor pointer");
+    if (loss_weights[11] != 1.f) return fail(c, SR_ERR_ARG, "the warp loss weight must be 1 (reference TecoGAN.py:130); other values are not built");
     if ((rc = train_init(c))) {
         train_free(c);
         return rc;
     }
     sr_train_state* T = c->train;
+    if (!T->act.count("pp") && (rc = talloc(c, "pp", (size_t)c->max_batch * c->h * c->w * 48))) return rc;
+    return SR_OK;
+}
+
+// The combined step on DEVICE tensors, everything on the generator's stream (the caller has swapped the discriminator's
+// stream): generator forward (taped), discriminator on [est_tm1, est, next_est, warp(est_tm1), est, next_hat_est, bic x 3]
+// with batch statistics, the weighted losses, both backward passes.  d_hr / d_pp: ground truth and ping-pong target.
+static int tecogan_grads_core(sr_ctx* c, sr_disc* d, int B, const float* d_lr_t, const float* d_lr_tm1, const float* d_est_tm1,
+                              const float* d_next_est, const float* d_next_hat, const float* d_bic_past, const float* d_bic_pres,
+                              const float* d_bic_fut, const float* d_hr, const float* const* d_feat, const float* d_pp, const float* lw,
+                              float* losses) {
+    sr_train_state* T = c->train;
     c->clip_active = false;
     hipStream_t st = c->stream;
     const int H = c->h, W = c->w;
-    const size_t nlr = (size_t)B * H * W * 3 * 4, nhr = nlr * 16;
-    if (!T->act.count("pp") && (rc = talloc(c, "pp", (size_t)c->max_batch * H * W * 48))) return rc;
-    // everything of this call runs on the generator's stream, the discriminator's kernels included
-    HIPCHK(c, hipStreamSynchronize(d->stream));
-    struct StreamSwap {
-        sr_disc* d;
-        hipStream_t old;
-        ~StreamSwap() { d->stream = old; }
-    } swap_guard{d, d->stream};
-    d->stream = st;
-    HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, lr_tm1, nlr, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(T->act["hr"], hr_t, nhr, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(T->act["pp"], pp_target, nhr, hipMemcpyHostToDevice, st));
-    const float* host_in[9] = {nullptr, nullptr, next_est, nullptr, nullptr, next_hat_est, bic_past, bic_pres, bic_fut};
-    for (int i = 0; i < 9; ++i)
-        if (host_in[i]) HIPCHK(c, hipMemcpyAsync(d->in9[i], host_in[i], nhr, hipMemcpyHostToDevice, st));
-    const float* feat[4];
-    for (int k = 0; k < 4; ++k) {
-        if (!d_targets[k]) return fail(c, SR_ERR_ARG, "feature-map target %d is NULL", k);
-        HIPCHK(c, hipMemcpyAsync(d->featT[k], d_targets[k], (size_t)B * (d->H >> (k + 1)) * (d->W >> (k + 1)) * DISC_COUT[k] * 4, hipMemcpyHostToDevice, st));
-        feat[k] = d->featT[k];
-    }
-    // generator forward (taped)
+    int rc;
     Tape t{c, T, B, c->prec, st};
     t.hr_warp_out = c->d_hr_warp;
-    if ((rc = train_forward(t, 1, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
-    if ((rc = train_forward(t, 2, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
+    if ((rc = train_forward(t, 1, d_lr_t, d_lr_tm1, d_est_tm1, c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
+    if ((rc = train_forward(t, 2, d_lr_t, d_lr_tm1, d_est_tm1, c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
     const float* est = c->d_est[1];
     // discriminator on the generated triplet: forward, losses, backward down to its 27 input channels
-    const sr::Ptr9 p9 = {{c->d_est[0], est, d->in9[2], c->d_hr_warp, est, d->in9[5], d->in9[6], d->in9[7], d->in9[8]}};
+    const sr::Ptr9 p9 = {{d_est_tm1, est, d_next_est, c->d_hr_warp, est, d_next_hat, d_bic_past, d_bic_pres, d_bic_fut}};
     if ((rc = disc_forward(d, B, p9, true, false))) return fail(c, rc, "%s", d->err.c_str());
     LAUNCHCHK(c, "bce", launch_bce(d->logit, nullptr, 1.f, B, lw[1], d->prob, d->dlogit, d->d_loss, st));   // target D_ones (TecoGAN.py:473)
-    if ((rc = disc_backward(d, B, feat, lw + 2, true, true))) return fail(c, rc, "%s", d->err.c_str());
+    if ((rc = disc_backward(d, B, d_feat, lw + 2, true, true))) return fail(c, rc, "%s", d->err.c_str());
     // generator backward from the weighted losses on its output + what came back through the discriminator
     const long npix = (long)B * 16 * H * W;
     // (the discriminator's reduction workspace is sized for its 64-channel HR tensor: 16x what this needs)
-    LAUNCHCHK(c, "teco_est_grad", launch_teco_est_grad(est, T->act["hr"], T->act["pp"], d->gS, t.a("s_out"), t.a("g_est"), d->red,
+    LAUNCHCHK(c, "teco_est_grad", launch_teco_est_grad(est, d_hr, d_pp, d->gS, t.a("s_out"), t.a("g_est"), d->red,
                                                        d->d_loss + 5, d->d_loss + 6, npix, lw[0], lw[10], st));
     t.ext_g_est = true;
     t.g27 = d->gS;
-    if ((rc = train_backward(t, c->d_lr_t, c->d_lr_tm1, c->d_est[0], T->act["hr"], est, c->d_lr_warp, c->d_flow))) return rc;
+    if ((rc = train_backward(t, d_lr_t, d_lr_tm1, d_est_tm1, d_hr, est, c->d_lr_warp, c->d_flow))) return rc;
     float dl[8] = {0}, gl[2] = {0};
     HIPCHK(c, hipMemcpyAsync(dl, d->d_loss, sizeof dl, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(gl, T->d_loss, sizeof gl, hipMemcpyDeviceToHost, st));
@@ -929,13 +912,120 @@ int sr_tecogan_grads(sr_ctx* c, sr_disc* d, int B, const float* lr_t, const floa
     return SR_OK;
 }
 
+// runs the discriminator's kernels on the generator's stream for the lifetime of the guard
+struct DiscStreamSwap {
+    sr_disc* d;
+    hipStream_t old;
+    DiscStreamSwap(sr_disc* d_, hipStream_t st) : d(d_), old(d_->stream) { d->stream = st; }
+    ~DiscStreamSwap() { d->stream = old; }
+};
+
+int sr_tecogan_grads(sr_ctx* c, sr_disc* d, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1,
+                     const float* next_est, const float* next_hat_est, const float* bic_past, const float* bic_pres,
+                     const float* bic_fut, const float* hr_t, const float* const* d_targets, const float* pp_target,
+                     const float* loss_weights, float* losses) {
+    int rc = tecogan_ready(c, d, B, loss_weights);
+    if (rc) return rc;
+    if (!lr_t || !lr_tm1 || !est_tm1 || !next_est || !next_hat_est || !bic_past || !bic_pres || !bic_fut || !hr_t || !d_targets || !pp_target)
+        return fail(c, SR_ERR_ARG, "NULL tensor pointer");
+    sr_train_state* T = c->train;
+    hipStream_t st = c->stream;
+    const size_t nlr = (size_t)B * c->h * c->w * 3 * 4, nhr = nlr * 16;
+    HIPCHK(c, hipStreamSynchronize(d->stream));
+    DiscStreamSwap swap_guard(d, st);
+    HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, lr_tm1, nlr, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(T->act["hr"], hr_t, nhr, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(T->act["pp"], pp_target, nhr, hipMemcpyHostToDevice, st));
+    const float* host_in[9] = {nullptr, nullptr, next_est, nullptr, nullptr, next_hat_est, bic_past, bic_pres, bic_fut};
+    for (int i = 0; i < 9; ++i)
+        if (host_in[i]) HIPCHK(c, hipMemcpyAsync(d->in9[i], host_in[i], nhr, hipMemcpyHostToDevice, st));
+    const float* feat[4];
+    for (int k = 0; k < 4; ++k) {
+        if (!d_targets[k]) return fail(c, SR_ERR_ARG, "feature-map target %d is NULL", k);
+        HIPCHK(c, hipMemcpyAsync(d->featT[k], d_targets[k], (size_t)B * (d->H >> (k + 1)) * (d->W >> (k + 1)) * DISC_COUT[k] * 4, hipMemcpyHostToDevice, st));
+        feat[k] = d->featT[k];
+    }
+    return tecogan_grads_core(c, d, B, c->d_lr_t, c->d_lr_tm1, c->d_est[0], d->in9[2], d->in9[5], d->in9[6], d->in9[7], d->in9[8],
+                              T->act["hr"], feat, T->act["pp"], loss_weights, losses);
+}
+
+static int tecogan_adam(sr_ctx* c, sr_disc* d, const float* d_gen_grads, const float* d_disc_grads, float grad_scale, float lr,
+                        float beta1, float beta2, float eps, int64_t t, int train_disc);
+
+// One whole pass of the adversarial loop body (reference TecoGAN.py:434-479) with every array uploaded ONCE and everything else
+// on the device: discriminator step on the real triplets (labels 1, fresh moments, Adam step t0 + 1), on the generated ones
+// (labels 0, t0 + 2), discriminator.predict on the real triplets (its feature maps become the targets, device to device),
+// two combined steps (t0 + 3, t0 + 4) against the batch-flipped ground truth as ping-pong target (TecoGAN.py:476).
+// Through the step-by-step entry points the same pass moves ~800 MB of host arrays (the real set three times, the feature
+// maps out and in again twice); here 15 arrays go up once.
+int sr_tecogan_iteration(sr_ctx* c, sr_disc* d, int B, const float* const* arrays, const float* loss_weights, float lr, float beta1,
+                         float beta2, float eps, int64_t t0, int train_disc, float* losses, float* disc_losses) {
+    int rc = tecogan_ready(c, d, B, loss_weights);
+    if (rc) return rc;
+    if (!arrays) return fail(c, SR_ERR_ARG, "NULL tensor pointer");
+    for (int i = 0; i < 15; ++i)
+        if (!arrays[i]) return fail(c, SR_ERR_ARG, "array %d is NULL", i);
+    if (t0 < 0) return fail(c, SR_ERR_ARG, "Adam iteration must be >= 0");
+    sr_train_state* T = c->train;
+    hipStream_t st = c->stream;
+    const size_t nlr = (size_t)B * c->h * c->w * 3 * 4, nhr = nlr * 16, img = nhr / (size_t)B;
+    HIPCHK(c, hipStreamSynchronize(d->stream));
+    DiscStreamSwap swap_guard(d, st);
+    // arrays: 0 lr, 1 prev_lr, 2 hr, 3 prev_hr, 4 next_hr, 5 prev_hat_hr, 6 next_hat_hr, 7 est, 8 prev_est, 9 next_est,
+    //         10 prev_hat_est, 11 next_hat_est, 12 bic, 13 prev_bic, 14 next_bic
+    if (d->it_buf.empty()) {
+        d->it_buf.assign(13, nullptr);
+        for (float*& p : d->it_buf)
+            if (hipMalloc((void**)&p, (size_t)d->max_batch * img) != hipSuccess) return fail(c, SR_ERR_HIP, "hipMalloc failed");
+    }
+    float** hb = d->it_buf.data();          // hb[i] = arrays[i + 2]
+    HIPCHK(c, hipMemcpyAsync(c->d_lr_t, arrays[0], nlr, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, arrays[1], nlr, hipMemcpyHostToDevice, st));
+    for (int i = 0; i < 13; ++i) HIPCHK(c, hipMemcpyAsync(hb[i], arrays[i + 2], nhr, hipMemcpyHostToDevice, st));
+    const float *hr = hb[0], *prev_hr = hb[1], *next_hr = hb[2], *prev_hat_hr = hb[3], *next_hat_hr = hb[4], *est = hb[5], *prev_est = hb[6],
+                *next_est = hb[7], *prev_hat_est = hb[8], *next_hat_est = hb[9], *bic = hb[10], *prev_bic = hb[11], *next_bic = hb[12];
+    for (int b = 0; b < B; ++b)             // np.flip(hr_batch, axis=0)
+        HIPCHK(c, hipMemcpyAsync((unsigned char*)T->act["pp"] + (size_t)b * img, (const unsigned char*)hr + (size_t)(B - 1 - b) * img, img,
+                                 hipMemcpyDeviceToDevice, st));
+    const sr::Ptr9 real = {{prev_hr, hr, next_hr, prev_hat_hr, hr, next_hat_hr, prev_bic, bic, next_bic}};
+    const sr::Ptr9 fake = {{prev_est, est, next_est, prev_hat_est, est, next_hat_est, prev_bic, bic, next_bic}};
+    float dl[2] = {0.f, 0.f};
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = disc_forward(d, B, k ? fake : real, true, true))) return fail(c, rc, "%s", d->err.c_str());
+        LAUNCHCHK(c, "bce", launch_bce(d->logit, nullptr, k ? 0.f : 1.f, B, 1.f, d->prob, d->dlogit, d->d_loss, st));
+        if ((rc = disc_backward(d, B, nullptr, nullptr, true, false))) return fail(c, rc, "%s", d->err.c_str());
+        HIPCHK(c, hipMemcpyAsync(&dl[k], d->d_loss, 4, hipMemcpyDeviceToHost, st));
+        if ((rc = disc_apply(d, nullptr, 1.f, lr, beta1, beta2, eps, t0 + 1 + k, 0, k == 0))) return fail(c, rc, "%s", d->err.c_str());
+    }
+    if ((rc = disc_forward(d, B, real, false, false))) return fail(c, rc, "%s", d->err.c_str());
+    const float* feat[4];
+    for (int k = 0; k < 4; ++k) {
+        HIPCHK(c, hipMemcpyAsync(d->featT[k], d->y[k], (size_t)B * (d->H >> (k + 1)) * (d->W >> (k + 1)) * DISC_COUT[k] * 4, hipMemcpyDeviceToDevice, st));
+        feat[k] = d->featT[k];
+    }
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = tecogan_grads_core(c, d, B, c->d_lr_t, c->d_lr_tm1, prev_est, next_est, next_hat_est, prev_bic, bic, next_bic, hr, feat,
+                                     T->act["pp"], loss_weights, losses)))
+            return rc;
+        if ((rc = tecogan_adam(c, d, nullptr, nullptr, 1.f, lr, beta1, beta2, eps, t0 + 3 + k, train_disc))) return rc;
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (disc_losses) {
+        disc_losses[0] = dl[0];
+        disc_losses[1] = dl[1];
+    }
+    return SR_OK;
+}
+
 // The optimizer step of tecogan.train_on_batch: Adam (Keras 2.2.4) with iteration `t` (the reference's ONE shared Adam,
 // TecoGAN.py:111: the caller keeps its counter) on the generator -- moments of tecogan's own train function, not those of
 // the generator pre-training -- and, when train_disc != 0, on the discriminator too: the reference compiles tecogan while
 // the discriminator is still trainable (TecoGAN.py:122 precedes :461), so its weights are among tecogan's collected
 // trainable weights and move with the combined loss.
-int sr_tecogan_apply(sr_ctx* c, sr_disc* d, const float* d_gen_grads, const float* d_disc_grads, float grad_scale, float lr,
-                     float beta1, float beta2, float eps, int64_t t, int train_disc) {
+static int tecogan_adam(sr_ctx* c, sr_disc* d, const float* d_gen_grads, const float* d_disc_grads, float grad_scale, float lr,
+                        float beta1, float beta2, float eps, int64_t t, int train_disc) {
     if (!c || !d) return fail(c, SR_ERR_ARG, "NULL argument");
     if (!c->train) return fail(c, SR_ERR_STATE, "no gradients: call sr_tecogan_grads first");
     if (t < 1) return fail(c, SR_ERR_ARG, "Adam iteration must be >= 1");
@@ -961,6 +1051,11 @@ int sr_tecogan_apply(sr_ctx* c, sr_disc* d, const float* d_gen_grads, const floa
             return fail(c, rc, "%s", d->err.c_str());
     }
     return SR_OK;
+}
+
+int sr_tecogan_apply(sr_ctx* c, sr_disc* d, const float* d_gen_grads, const float* d_disc_grads, float grad_scale, float lr,
+                     float beta1, float beta2, float eps, int64_t t, int train_disc) {
+    return tecogan_adam(c, d, d_gen_grads, d_disc_grads, grad_scale, lr, beta1, beta2, eps, t, train_disc);
 }
 
 // Both gradients of the last sr_tecogan_grads into DEVICE buffers (the all-reduce buffers of a data-parallel job).

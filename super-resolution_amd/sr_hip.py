@@ -86,6 +86,8 @@ SIGNATURES = {
     "sr_tecogan_grads": (C.c_int, [_vp, _vp, C.c_int] + [_vp] * 9 + [C.POINTER(_vp), _vp, _f32p, _f32p]),
     "sr_tecogan_apply": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_int]),
     "sr_tecogan_read_grads_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "sr_tecogan_iteration": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp), _f32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64,
+                                       C.c_int, _f32p, _f32p]),
     "sr_op_conv3x3_wgrad_noalloc": (C.c_int, [C.c_int] * 7 + [_vp] * 5),
     "sr_bench_conv": (C.c_int, [C.c_int] * 10 + [C.POINTER(C.c_float)]),
 }
@@ -506,6 +508,25 @@ def tecogan_apply(ctx, disc, t, lr=5e-5, beta_1=0.9, beta_2=0.999, epsilon=1e-7,
                   grad_scale=1.0):
     _check(lib().sr_tecogan_apply(ctx._h, disc._h, _vp(d_gen_grads) if d_gen_grads else None, _vp(d_disc_grads) if d_disc_grads else None,
                                   grad_scale, lr, beta_1, beta_2, epsilon, int(t), int(bool(train_disc))), ctx._h)
+
+
+ITERATION_ARRAYS = ("lr", "prev_lr", "hr", "prev_hr", "next_hr", "prev_hat_hr", "next_hat_hr", "est", "prev_est", "next_est",
+                    "prev_hat_est", "next_hat_est", "bic", "prev_bic", "next_bic")
+
+
+def tecogan_iteration(ctx, disc, batch, loss_weights, t0, lr=5e-5, beta_1=0.9, beta_2=0.999, epsilon=1e-7, train_disc=True):
+    """One pass of the adversarial loop body (include/sr_hip.h sr_tecogan_iteration); batch: dict with the ITERATION_ARRAYS keys.
+    Returns (the 13 losses of the last combined step, the two discriminator losses)."""
+    B = int(np.shape(batch["lr"])[0])
+    ls, hs = ctx._shapes(B)
+    arrs = [ctx._check_in(batch[k], ls if k in ("lr", "prev_lr") else hs, k) for k in ITERATION_ARRAYS]
+    lw = _f32(np.asarray(loss_weights, np.float32))
+    if lw.shape != (12,):
+        raise ValueError("loss_weights: expected the 12 weights of tecogan.compile")
+    losses, dl = (C.c_float * 13)(), (C.c_float * 2)()
+    _check(lib().sr_tecogan_iteration(ctx._h, disc._h, B, _ptr_array(arrs), lw.ctypes.data_as(_f32p), lr, beta_1, beta_2, epsilon, int(t0),
+                                      int(bool(train_disc)), losses, dl), ctx._h)
+    return list(losses), list(dl)
 
 
 def tecogan_read_grads_dev(ctx, disc, d_gen_out=None, d_disc_out=None):

@@ -202,6 +202,7 @@ def test_tecogan_adversarial_stage(tmp_path, weights7):
     assert np.abs(b['prev_hat_hr'][2] - taps['hr_warp'][0]).max() <= 2e-4
     # one iteration against the oracle, from the same batch arrays
     t.make_gan_batch = lambda _hr: b
+    t.step_by_step = True                       # the five model calls of the reference; the fused native pass is compared below
     moments = ({}, {}, {}, {})
     gen_w, disc_w, its, want_l = rd.gan_iteration(dict(weights7), dict(dw), b, 0, moments)
     loss = t.gan_iteration(hr)
@@ -220,7 +221,17 @@ def test_tecogan_adversarial_stage(tmp_path, weights7):
                 continue
             assert np.abs(a - w0[n]).max() > 0, n
             assert d.mean() <= 0.05 * step and d.max() <= 2.01 * step, (n, d.mean(), d.max())
+    # the same pass as ONE native call (sr_tecogan_iteration) from the same start: the same weights, bit for bit
+    t2 = build('tecogan', (16, 16, 3), tmp_path, weights7)
+    t2._load_pretrained()
+    t2.discriminator.set_weights(list(dw.values()))
+    t2.make_gan_batch = lambda _hr: b
+    loss2 = t2.gan_iteration(hr)
+    assert t2.opt.iterations == 4 and np.allclose(loss2, loss, rtol=1e-6, atol=1e-9)
+    for x, y in zip(t2.generator.get_weights() + t2.discriminator.get_weights(), t.generator.get_weights() + t.discriminator.get_weights()):
+        np.testing.assert_array_equal(x, y)
     # the stage: pretrained discriminator => no pre-training (TecoGAN.py:148-152), 2 iterations, both checkpoints
+    t.step_by_step = False
     del t.make_gan_batch
     os.makedirs(tmp_path / 'clips')
     np.save(tmp_path / 'clips' / '0.npy', (rn.synth_clip(31, 6, 80, 80, scale=4) * 255).astype(np.uint8))

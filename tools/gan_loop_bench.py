@@ -20,6 +20,7 @@ def main():
     t = TecoGAN((H // 4, H // 4, 3), (H, H, 3), "/tmp/gan_out", cfg)
     t.build()
     hr = np.stack([synth.synth_clip(50 + k, c, H, H, scale=4) for k in range(n)]).astype(np.float32)
+    t.step_by_step = "--step-by-step" in sys.argv
     for it in range(4):
         t0 = time.perf_counter()
         b = t.make_gan_batch(hr)
