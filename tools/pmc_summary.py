@@ -67,7 +67,7 @@ def main():
         return
     if sys.argv[1] == "counters":
         for ctr in sys.argv[3:]:
-            for k, (v, n) in sorted(per_kernel(sys.argv[2], ctr).items(), key=lambda kv: -kv[1][0] * kv[1][1])[:12]:
+            for k, (v, n) in sorted(per_kernel(sys.argv[2], ctr).items(), key=lambda kv: -kv[1][0] * kv[1][1]):
                 print(f"{ctr:32s} {k[:90]:90s} launches {n:5d} mean per launch {v:.4g}")
         return
     fetch = per_kernel(sys.argv[2], "FETCH_SIZE")
