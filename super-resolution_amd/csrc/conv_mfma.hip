@@ -337,15 +337,41 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[G::MT][NT], const C
 // nine shifted P planes.  The accumulator layout IS the MFMA B-operand layout up to a permutation of K
 // (lane (pixel r, half h) holds channels n*32 + 8g + 4h + j), which the host applies to the packed
 // projection weights, so no data moves between the two MFMA stages.
+// bias4[n][g] = a.bias[n*32 + 8g + 4h ..+3] and pwr[k] = the lane's projection-weight vectors, loaded ONCE at kernel start: as
+// global loads inside the epilogue they queue behind the weight-tap prefetch in the in-order vmcnt counter and their latency
+// is exposed once per pass
+template <int PREC>
+struct ProjRegs {
+    static constexpr int NW = PREC == P_BF16 ? 4 : 8;
+    f32x4 bias4[2][4];
+    u32x4 pw[NW];
+};
+
 template <class G, int PREC>
-__device__ __forceinline__ void epilogue_proj(const f32x16 (&acc)[G::MT][2], const ConvArgs& a, int pass, int b, int y0,
-                                              int x0, int wave, int lane) {
+__device__ __forceinline__ void proj_regs_load(ProjRegs<PREC>& pr, const ConvArgs& a, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pr.bias4[n][g] = *reinterpret_cast<const f32x4*>(a.bias + (blockIdx.y * 2 + n) * 32 + 8 * g + 4 * h);
+    if (a.proj_w) {
+        const u32x4* pw = reinterpret_cast<const u32x4*>(a.proj_w) + lane;
+#pragma unroll
+        for (int k = 0; k < ProjRegs<PREC>::NW; ++k) pr.pw[k] = pw[k * 64];
+    } else {
+#pragma unroll
+        for (int k = 0; k < ProjRegs<PREC>::NW; ++k) pr.pw[k] = u32x4{0u, 0u, 0u, 0u};
+    }
+}
+
+template <class G, int PREC>
+__device__ __forceinline__ void epilogue_proj(const f32x16 (&acc)[G::MT][2], const ConvArgs& a, const ProjRegs<PREC>& pr, int pass, int b,
+                                              int y0, int x0, int wave, int lane) {
     static_assert(G::MT == 1, "transposed-conv tiles have one row per wave");
     const int r = lane & 31, h = lane >> 5;
     const int H = a.H, W = a.W;
     const float slope = a.act == A_RELU ? 0.f : (a.act == A_LRELU ? 0.2f : 1.f);
     const int iy = y0 + wave, ix = x0 + r;
-    const u32x4* pw = reinterpret_cast<const u32x4*>(a.proj_w) + lane;
     f32x16 p;
 #pragma unroll
     for (int i = 0; i < 16; ++i) p[i] = 0.f;
@@ -357,7 +383,7 @@ __device__ __forceinline__ void epilogue_proj(const f32x16 (&acc)[G::MT][2], con
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int g = 2 * s + q;
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + n * 32 + 8 * g + 4 * h);
+                const f32x4 bias = pr.bias4[n][g];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float t = acc[0][n][4 * g + j] + bias[j];
@@ -366,8 +392,8 @@ __device__ __forceinline__ void epilogue_proj(const f32x16 (&acc)[G::MT][2], con
             }
             const int kidx = n * 2 + s;
             if constexpr (PREC == P_FP32) {
-                const f32x4 w0 = __builtin_bit_cast(f32x4, pw[(kidx * 2 + 0) * 64]);
-                const f32x4 w1 = __builtin_bit_cast(f32x4, pw[(kidx * 2 + 1) * 64]);
+                const f32x4 w0 = __builtin_bit_cast(f32x4, pr.pw[kidx * 2 + 0]);
+                const f32x4 w1 = __builtin_bit_cast(f32x4, pr.pw[kidx * 2 + 1]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) p = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], v[e], p, 0, 0, 0);
 #pragma unroll
@@ -380,13 +406,13 @@ __device__ __forceinline__ void epilogue_proj(const f32x16 (&acc)[G::MT][2], con
                     xl[e] = (__bf16)(v[e] - (float)xh[e]);
                 }
                 if constexpr (PREC == P_BF16X3) {
-                    const bf16x8 wh = __builtin_bit_cast(bf16x8, pw[(kidx * 2 + 0) * 64]);
-                    const bf16x8 wl = __builtin_bit_cast(bf16x8, pw[(kidx * 2 + 1) * 64]);
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, pr.pw[kidx * 2 + 0]);
+                    const bf16x8 wl = __builtin_bit_cast(bf16x8, pr.pw[kidx * 2 + 1]);
                     p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, p, 0, 0, 0);
                     p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, p, 0, 0, 0);
                     p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, p, 0, 0, 0);
                 } else {
-                    const bf16x8 wh = __builtin_bit_cast(bf16x8, pw[kidx * 64]);
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, pr.pw[kidx]);
                     p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, p, 0, 0, 0);
                 }
             }
@@ -401,6 +427,36 @@ __device__ __forceinline__ void epilogue_proj(const f32x16 (&acc)[G::MT][2], con
             *reinterpret_cast<f32x4*>(op + 8 * g) = o;
         }
     }
+}
+
+// Plain epilogue of the 64-channel transposed conv (SRNet conv2d_transpose_1): bias from registers, activation as one max, 16-byte
+// stores of this lane's four channels; anything else (narrow stores, residual, tanh) takes the general epilogue_t.
+template <class G>
+__device__ __forceinline__ void epilogue_convt(const f32x16 (&acc)[G::MT][2], const ConvArgs& a, const f32x4 (&bias4)[2][4], int pass, int b,
+                                               int y0, int x0, int wave, int r, int h) {
+    const bool lean = a.out_f32 && !a.res && a.cout_store == (int)(blockIdx.y * 2 + 2) * 32 && (a.out_cs & 3) == 0 &&
+                      (a.act == A_RELU || a.act == A_LRELU || a.act == A_NONE);
+    if (!lean) {
+        epilogue<G, M_CONVT, 2, true>(acc, a, pass, b, y0, x0, wave, r, h);
+        return;
+    }
+    const float slope = a.act == A_RELU ? 0.f : (a.act == A_LRELU ? 0.2f : 1.f);
+    const int iy = y0 + wave, ix = x0 + r;
+    if (iy >= a.H || ix >= a.W) return;
+    const int oy = 2 * iy + (pass >> 1), ox = 2 * ix + (pass & 1);
+    float* op = reinterpret_cast<float*>(a.out) + (((size_t)b * 2 * a.H + oy) * 2 * a.W + ox) * a.out_cs + blockIdx.y * 64 + 4 * h;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = acc[0][n][4 * g + j] + bias4[n][g][j];
+                o[j] = fmaxf(t, slope * t);
+            }
+            *reinterpret_cast<f32x4*>(op + n * 32 + 8 * g) = o;
+        }
 }
 
 template <class G, int NT>
@@ -477,8 +533,11 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
             gstep += pass_ntaps(MODE, P) * STEPS;                                                               \
         }                                                                                                       \
         if constexpr (NT == 2) {                                                                                \
-            if (a.proj_w) epilogue_proj<G, PREC>(acc, a, P, b, y0, x0, wave, lane);                             \
-            else epilogue<G, MODE, NT, true>(acc, a, P, b, y0, x0, wave, r, h);                                 \
+            if (a.proj_w) {                                                                                     \
+                ProjRegs<PREC> pr;                                                                              \
+                proj_regs_load<G, PREC>(pr, a, lane);                                                           \
+                epilogue_proj<G, PREC>(acc, a, pr, P, b, y0, x0, wave, lane);                                   \
+            } else epilogue<G, MODE, NT, true>(acc, a, P, b, y0, x0, wave, r, h);                               \
         } else {                                                                                                \
             epilogue<G, MODE, NT, true>(acc, a, P, b, y0, x0, wave, r, h);                                      \
         }
@@ -1092,6 +1151,8 @@ __global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) 
         for (int it = 0; it < WIT; ++it)
             *reinterpret_cast<u32x4*>(smem_b + (size_t)buf * TAPV * 16 + (it * 256 + tid) * 16) = regs_w[it];
     };
+    ProjRegs<PREC> pr;
+    proj_regs_load<G, PREC>(pr, a, lane);
 
     {
         u32x4 regs[G::ITER];
@@ -1140,8 +1201,8 @@ __global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) 
             }
         }
         if (last) {
-            if (a.proj_w) epilogue_proj<G, PREC>(acc, a, pass, b, y0, x0, wave, lane);
-            else epilogue<G, M_CONVT, 2, true>(acc, a, pass, b, y0, x0, wave, r, h);
+            if (a.proj_w) epilogue_proj<G, PREC>(acc, a, pr, pass, b, y0, x0, wave, lane);
+            else epilogue_convt<G>(acc, a, pr.bias4, pass, b, y0, x0, wave, r, h);
         }
         if (q + 1 < 9) __syncthreads();   // tap q+1 is in LDS for every wave; tap q's buffer is free
     };
