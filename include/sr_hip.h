@@ -176,6 +176,10 @@ int sr_op_space_to_depth(int device, int B, int H, int W, int C, int bs, const f
  * (weights [-3,19,19,-3]/32 on each block of 4), fused into one 8 x 8 gather.  hr (N,H,W,C), H and W multiples
  * of 4 -> lr (N,H/4,W/4,C).  Host pointers. */
 int sr_op_blur_cubic_downscale(int device, int N, int H, int W, int C, const float* hr, float* lr);
+/* The bicubic x4 image of the reference's adversarial batch and metrics (TecoGAN.py:313, FRVSR.py:304): cv2.resize(lr, 4x,
+ * INTER_CUBIC), 4-tap cubic (a = -0.75) at the fixed fractions of an exact x4 enlargement, border taps clamped.
+ * lr (N,h,w,C) -> out (N,4h,4w,C).  Host pointers. */
+int sr_op_cubic_upscale4(int device, int N, int h, int w, int C, const float* lr, float* out);
 
 /* ---- training step (SURVEY.md section 8 f, rank 1) ------------------------------------------------
  * Replaces frvsr.train_on_batch([lr_t, lr_tm1, est_tm1], [hr_t, lr_t]) (reference FRVSR.py:154-156)

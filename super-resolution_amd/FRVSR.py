@@ -22,7 +22,7 @@ import yaml
 import dp
 import sr_hip
 from layers import (Adam, FNet, GeneratorCore, GeneratorModel, Space2Depth, SRNet, Upscaling, Warp)
-from utils import (blur_cubic_downscale, box_downscale, cubic_upscale4, denormalize, get_frames, get_videos, load_clip,
+from utils import (blur_cubic_downscale, box_downscale, denormalize, get_frames, get_videos, load_clip,
                    merge_tiles, normalize, psnr, shard_range, split_tiles, ssim)
 
 
@@ -175,7 +175,7 @@ class FrameRecurrentVideoSR(object):
                 hr0 = normalize(hr[0, 0]) if hr.dtype == np.uint8 else hr[0, 0]
                 lr0 = sr_hip.blur_cubic_downscale(hr0[None], device=self.core.device)[0]
                 est, _ = gen.predict([lr0[None], np.zeros_like(lr0)[None], np.zeros_like(hr0)[None]])
-                bic = cubic_upscale4(lr0[None])[0]
+                bic = sr_hip.cubic_upscale4(lr0[None], device=self.core.device)[0]
                 print('[INFO] %s PSNR: %f \t Bicubic PSNR: %f' % (label, psnr(est[0], hr0), psnr(bic, hr0)))
                 window = np.concatenate([denormalize(np.clip(bic, 0, 1)), denormalize(np.clip(est[0], 0, 1)), denormalize(hr0)], axis=0)
                 np.save(os.path.join(samples_dir, 'Sample_%d.npy' % i), window)
@@ -219,7 +219,7 @@ class FrameRecurrentVideoSR(object):
                 q = ssim(hr_frames[t], out[t])
                 stats['psnr'].append(p)
                 stats['ssim'].append(q)
-                bic = cubic_upscale4(lr_frames[t:t + 1])[0]    # the reference's bicubic baseline (FRVSR.py:304,322,328)
+                bic = sr_hip.cubic_upscale4(lr_frames[t:t + 1], device=self.core.device)[0]    # the reference's bicubic baseline (FRVSR.py:304,322,328)
                 stats['bic_psnr'].append(psnr(bic, hr_frames[t]))
                 stats['bic_ssim'].append(ssim(bic, hr_frames[t]))
                 if metrics_file is not None:    # the reference's row (FRVSR.py:339)

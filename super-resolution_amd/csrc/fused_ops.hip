@@ -557,6 +557,64 @@ hipError_t launch_denorm_u8(const float* est, unsigned char* out, int B, int HH,
     return hipGetLastError();
 }
 
+// cv2.resize(lr, 4x, INTER_CUBIC) (reference TecoGAN.py:313, FRVSR.py:304): destination pixel d samples the source at
+// (d + 0.5) / 4 - 0.5, i.e. phase d & 3 has the fixed fraction {0.625, 0.875, 0.125, 0.375} and first tap (d >> 2) - 2 + (phase >> 1);
+// 4-tap cubic kernel, a = -0.75, the last weight the remainder to 1, taps clamped to the border (utils.cubic_upscale4, parity
+// unpinned against cv2).  Rows first, then columns, products and sums in the numpy restatement's order and without fused
+// multiply-adds, so the two agree to the last bit.  wt: [4 phases][4 taps].
+struct CubicW {
+    float w[4][4];
+};
+__global__ void cubic_up4_kernel(const float* __restrict__ lr, float* __restrict__ out, int N, int h, int w, int C, CubicW cw) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)N * 4 * h * 4 * w * C;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    long p = idx / C;
+    const int ox = (int)(p % (4 * w));
+    p /= 4 * w;
+    const int oy = (int)(p % (4 * h));
+    const int n = (int)(p / (4 * h));
+    const int py = oy & 3, px = ox & 3;
+    const int y0 = (oy >> 2) - 2 + (py >> 1), x0 = (ox >> 2) - 2 + (px >> 1);
+    const float* img = lr + (size_t)n * h * w * C + c;
+    float col[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xs = min(max(x0 + j, 0), w - 1);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ys = min(max(y0 + i, 0), h - 1);
+            acc = __fadd_rn(acc, __fmul_rn(img[((size_t)ys * w + xs) * C], cw.w[py][i]));
+        }
+        col[j] = acc;
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __fadd_rn(acc, __fmul_rn(col[j], cw.w[px][j]));
+    out[idx] = acc;
+}
+
+hipError_t launch_cubic_up4(const float* lr, float* out, int N, int h, int w, int C, hipStream_t s) {
+    CubicW cw;
+    const double a = -0.75;
+    const double frac[4] = {0.625, 0.875, 0.125, 0.375};
+    for (int ph = 0; ph < 4; ++ph) {
+        const double t = frac[ph];
+        const double w0 = ((a * (t + 1) - 5 * a) * (t + 1) + 8 * a) * (t + 1) - 4 * a;
+        const double w1 = ((a + 2) * t - (a + 3)) * t * t + 1;
+        const double w2 = ((a + 2) * (1 - t) - (a + 3)) * (1 - t) * (1 - t) + 1;
+        cw.w[ph][0] = (float)w0;
+        cw.w[ph][1] = (float)w1;
+        cw.w[ph][2] = (float)w2;
+        cw.w[ph][3] = (float)(1.0 - (w0 + w1 + w2));
+    }
+    const long total = (long)N * 16 * h * w * C;
+    hipLaunchKernelGGL(cubic_up4_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, lr, out, N, h, w, C, cw);
+    return hipGetLastError();
+}
+
 hipError_t launch_blur_cubic_down4(const float* hr, float* lr, int N, int H, int W, int C, hipStream_t s) {
     const long total = (long)N * (H / 4) * (W / 4) * C;
     hipLaunchKernelGGL(blur_cubic_down4_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, hr, lr, N, H, W, C);

@@ -108,6 +108,7 @@ hipError_t launch_teco_epilogue(float* est, const float* lr_t, int B, int H, int
 // out[i] = in[i] / 255 (reference utils.py:57-58 normalize), n elements
 hipError_t launch_u8_normalize(const unsigned char* in, float* out, size_t n, hipStream_t s);
 hipError_t launch_blur_cubic_down4(const float* hr, float* lr, int N, int H, int W, int C, hipStream_t s);
+hipError_t launch_cubic_up4(const float* lr, float* out, int N, int h, int w, int C, hipStream_t s);
 
 // dense [B,rows,cols,ch] <-> zero-padded [B,rows_p,cols_p,ch] (pad mode of sr_create_padded: bottom / right padding)
 hipError_t launch_pad_copy(const float* in, float* out, int B, int rows, int cols, int ch, int rows_p, int cols_p, hipStream_t s);

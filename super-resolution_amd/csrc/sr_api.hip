@@ -1228,6 +1228,12 @@ int sr_op_blur_cubic_downscale(int device, int N, int H, int W, int C, const flo
     });
 }
 
+int sr_op_cubic_upscale4(int device, int N, int h, int w, int C, const float* lr, float* out) {
+    if (N < 1 || h < 1 || w < 1 || C < 1) return fail(nullptr, SR_ERR_ARG, "non-positive dimension");
+    const size_t n_in = (size_t)N * h * w * C;
+    return simple_op(device, n_in, n_in * 16, lr, out, [&](const float* a, float* o) { return launch_cubic_up4(a, o, N, h, w, C, nullptr); });
+}
+
 int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, int Cin, int Cout, int residual,
                   int iters, float* ms_per_launch) {
     int rc = op_prologue(device);

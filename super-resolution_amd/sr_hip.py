@@ -56,6 +56,7 @@ SIGNATURES = {
     "sr_op_warp": (C.c_int, [C.c_int] * 5 + [_vp, _vp, _vp]),
     "sr_op_space_to_depth": (C.c_int, [C.c_int] * 6 + [_vp, _vp]),
     "sr_op_blur_cubic_downscale": (C.c_int, [C.c_int] * 5 + [_vp, _vp]),
+    "sr_op_cubic_upscale4": (C.c_int, [C.c_int] * 5 + [_vp, _vp]),
     "sr_train_param_count": (C.c_int, [_vp, _i64p]),
     "sr_train_grads": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _f32p]),
     "sr_train_grads_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _f32p]),
@@ -604,6 +605,15 @@ def blur_cubic_downscale(hr, device=0):
         raise ValueError("HR height and width must be multiples of 4")
     out = np.empty((N, H // 4, W // 4, Cc), np.float32)
     _check(lib().sr_op_blur_cubic_downscale(device, N, H, W, Cc, _ptr(hr), _ptr(out)))
+    return out
+
+
+def cubic_upscale4(lr, device=0):
+    """[N,h,w,C] -> [N,4h,4w,C]: cv2.resize(..., INTER_CUBIC) x4 on the GPU (same arithmetic as utils.cubic_upscale4)."""
+    lr = _f32(lr)
+    N, h, w, Cc = lr.shape
+    out = np.empty((N, 4 * h, 4 * w, Cc), np.float32)
+    _check(lib().sr_op_cubic_upscale4(device, N, h, w, Cc, _ptr(lr), _ptr(out)))
     return out
 
 

@@ -219,6 +219,20 @@ def test_error_paths(sh):
     ctx.close()
 
 
+@pytest.mark.parametrize("N,h,w,C", [(2, 4, 6, 3), (1, 1, 1, 3), (3, 32, 32, 3), (1, 2, 9, 1), (1, 45, 80, 3)])
+def test_cubic_upscale4(sh, N, h, w, C):
+    """The bicubic x4 image of the adversarial batch / the metrics baseline (TecoGAN.py:313, FRVSR.py:304) against the numpy
+    restatement: same weights, same order of products and sums, no fused multiply-adds."""
+    import utils
+    lr = rnd(22, N, h, w, C, lo=0.0, hi=1.0)
+    got = sh.cubic_upscale4(lr)
+    want = utils.cubic_upscale4(lr)
+    assert got.shape == (N, 4 * h, 4 * w, C)
+    assert np.abs(got - want).max() <= 1e-6
+    const = np.full((1, 3, 5, 3), 0.37, np.float32)              # weights sum to one, borders clamp
+    assert np.abs(sh.cubic_upscale4(const) - 0.37).max() <= 1e-6
+
+
 @pytest.mark.parametrize("N,H,W,C", [(2, 16, 24, 3), (1, 4, 4, 3), (3, 64, 64, 3), (1, 8, 12, 1), (1, 256, 256, 3)])
 def test_blur_cubic_downscale(sh, N, H, W, C):
     """LR synthesis of the reference's drivers (FRVSR.py:117-119, 274-277) as one fused gather against the numpy
