@@ -120,13 +120,30 @@ __host__ __device__ constexpr int pass_tap(int mode, int pass, int t) {
     return 4;
 }
 
+// vector v of a staged chunk -> (halo pixel p, 16-byte piece `part` of its channel row).  Pixel major by default; pm (planar
+// inputs staged whole, the transposed conv): plane major, so that consecutive threads read consecutive 16-byte units of ONE
+// plane (whole 128-byte lines) instead of four pieces of each of four planes
+template <class G>
+__device__ __forceinline__ void vec_map(int v, int pm, int& p, int& part) {
+    if (pm) {
+        constexpr int PER = G::NPIX * 4;
+        const int pl = v / PER, rem = v - pl * PER;
+        p = rem >> 2;
+        part = pl * 4 + (rem & 3);
+    } else {
+        p = v / G::VPP;
+        part = v % G::VPP;
+    }
+}
+
 template <class G, int PREC>
 __device__ __forceinline__ void stage_load(u32x4 (&regs)[G::ITER], const unsigned char* inb, int c, int cin_p,
-                                           int y0, int x0, int H, int W, int tid, int planar = 0) {
+                                           int y0, int x0, int H, int W, int tid, int planar = 0, int pm = 0) {
 #pragma unroll
     for (int it = 0; it < G::ITER; ++it) {
         const int v = tid + it * 256;
-        const int p = v / G::VPP, part = v % G::VPP;
+        int p, part;
+        vec_map<G>(v, pm, p, part);
         const int py = p / G::HCOLS, px = p - py * G::HCOLS;
         const int gy = y0 - 1 + py, gx = x0 - 1 + px;
         u32x4 val = {0u, 0u, 0u, 0u};
@@ -145,12 +162,13 @@ __device__ __forceinline__ void stage_load(u32x4 (&regs)[G::ITER], const unsigne
 // split: the vectors are units of a split-planar tensor (conv_trunk.hip) -- 8 bf16 hi or lo parts, already in the order
 // the packed weights (pack_entries kperm) expect -- and go to the hi / lo tile as they are
 template <class G, int PREC>
-__device__ __forceinline__ void stage_store(const u32x4 (&regs)[G::ITER], unsigned char* smem, int tid, int split = 0) {
+__device__ __forceinline__ void stage_store(const u32x4 (&regs)[G::ITER], unsigned char* smem, int tid, int split = 0, int pm = 0) {
 #pragma unroll
     for (int it = 0; it < G::ITER; ++it) {
         const int v = tid + it * 256;
         if (v < G::NV) {
-            const int p = v / G::VPP, part = v % G::VPP;
+            int p, part;
+            vec_map<G>(v, pm, p, part);
             if constexpr (PREC == P_BF16X3) {
                 if (split) {   // part = 4 * plane + unit; unit = 2 h + (0: hi, 1: lo); k-step = plane
                     const int u = part & 3;
@@ -1156,9 +1174,9 @@ __global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) 
 
     {
         u32x4 regs[G::ITER];
-        stage_load<G, PREC>(regs, inb, 0, a.cin_p, y0, x0, H, W, tid, a.in_planar);
+        stage_load<G, PREC>(regs, inb, 0, a.cin_p, y0, x0, H, W, tid, a.in_planar, a.in_planar);
         load_tap(0);
-        stage_store<G, PREC>(regs, smem, tid, a.in_split);
+        stage_store<G, PREC>(regs, smem, tid, a.in_split, a.in_planar);
     }
     store_tap(0);
     load_tap(1);

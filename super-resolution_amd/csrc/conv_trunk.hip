@@ -336,6 +336,289 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing DMA (into LDS) must not outlive the workgroup
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// conv2d_transpose_1 (reference layers.py:73: Conv2DTranspose 64 -> 64, 3x3, strides 2, 'same', ReLU) in the same style: split-planar
+// in (the trunk's output) and out (what conv2d_transpose_2's staging copies into LDS as it is).
+//   out[2i + ky, 2j + kx] += in[i, j] * w[ky, kx]  (full result minus its last row / column)
+// i.e. output parity (py, px) of input pixel (i, j) collects the taps with ky = py (mod 2), kx = px (mod 2) from the pixels
+// (i - ky/2, j - kx/2): 4 / 2 / 2 / 1 taps, nine per input pixel, no zero insertion.  A wave owns one row of 32 input pixels of an
+// 8 x 32 tile and keeps the four parity accumulators (32 channels of this workgroup's half) alive while K runs plane by plane;
+// per plane four shifted pixel fragments (hi, lo) feed 27 MFMAs.  Weights of the half (72 KiB) resident, 9 x 33 plane tiles
+// (19 KiB) double buffered by DMA; the epilogue of a finished tile (4 parities x 2 planes = 8 pieces: ReLU, hi / lo split, two
+// 16-byte stores) drains two pieces per plane step inside the next tile's MFMA stream.
+struct TKT {
+    static constexpr int TH = 8, TWX = 32;
+    static constexpr int HR = TH + 1, HC = TWX + 1;          // halo: one row above, one column to the left
+    static constexpr int NPIX = HR * HC;                     // 297
+    static constexpr int NUNIT = NPIX * 4;
+    static constexpr int NINST = (NUNIT + 63) / 64;          // 19 DMA wave-instructions
+    static constexpr int PER_WAVE = (NINST + 7) / 8;         // 3 (waves 0..2) or 2
+    static constexpr int A_BYTES = NINST * 1024;             // 19,456 per buffer
+    static constexpr int SCR_OFF = TK::W_BYTES + 2 * A_BYTES;   // per-wave 4 KiB store transpose scratch
+    static constexpr int LDS = SCR_OFF + 8 * 4096;           // 145,408
+};
+
+template <int NOMEM>
+__global__ __launch_bounds__(512, 2) void trunk_convT_kernel(const TrunkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const wl = smem;
+    unsigned char* const abuf = smem + TK::W_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int H = a.H, W = a.W;
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int half = slot & 1, pair = slot >> 1;
+    const int npairs = (int)(gridDim.x >> 4);
+    const int per_img = a.tiles_x * a.tiles_y;
+    const int ntiles = per_img * a.B;
+    const int per_xcd = (ntiles + 7) / 8;
+    const int t_end = min(ntiles, (xcd + 1) * per_xcd);
+    int t = xcd * per_xcd + pair;
+    if (t >= t_end) return;
+
+    const unsigned plane_bytes = (unsigned)(H * W * 64);
+    const unsigned oplane = 4u * plane_bytes;                 // output plane: 2H x 2W records
+    const unsigned orow = (unsigned)(2 * W) * 64u;
+
+    {   // resident weights: [plane][tap][hi, lo][lane] of this half
+        const unsigned char* wsrc = a.wpack + (size_t)half * TK::W_BYTES + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int k = wave + 8 * i;
+            __builtin_amdgcn_global_load_lds((const SR_AS1 void*)(wsrc + k * 1024), (SR_AS3 void*)(wl + k * 1024), 16, 0, 0);
+        }
+    }
+    int goff[TKT::PER_WAVE];
+    int pyx[TKT::PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < TKT::PER_WAVE; ++i) {
+        const int k = wave + 8 * i < TKT::NINST ? wave + 8 * i : wave + 8 * (i - 1);
+        const int u = k * 64 + lane;
+        const int p = u >> 2, sl = (u & 3) ^ ((p >> 2) & 3);
+        const int py = p / TKT::HC, px = p - py * TKT::HC;
+        goff[i] = (py * W + px) * 64 + sl * 16;
+        pyx[i] = u < TKT::NUNIT ? (px | (py << 8)) : (1 << 28);
+        asm volatile("" : "+v"(goff[i]), "+v"(pyx[i]));
+    }
+    const unsigned zoff = a.zero_off + (lane & 3) * 16;
+    const unsigned dump = a.out_tail + 256 + lane * 16;      // store lanes outside the image write behind the OUTPUT tensor
+    struct Tile {
+        unsigned off0, okm;
+        unsigned erow;   // output: offset of record (row 2 iy, column 2 x0) of the half's first plane + this lane's 16 bytes
+        int xlim;        // valid input columns from x0 on (0: the wave's row lies outside the image)
+    };
+    auto locate = [&](int tt) {
+        Tile q;
+        const int b = tt / per_img;
+        const int rem = tt - b * per_img;
+        const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+        const int y0 = ty * TKT::TH - 1, x0 = tx * TKT::TWX - 1;
+        q.off0 = (unsigned)(b * 4) * plane_bytes + (unsigned)((y0 * W + x0) * 64);
+        q.okm = 0;
+#pragma unroll
+        for (int i = 0; i < TKT::PER_WAVE; ++i) {
+            const unsigned gy = (unsigned)(y0 + (pyx[i] >> 8)), gx = (unsigned)(x0 + (pyx[i] & 255));
+            q.okm |= ((gy < (unsigned)H) & (gx < (unsigned)W)) ? (1u << i) : 0u;
+        }
+        const int iy = y0 + 1 + wave;
+        q.erow = (unsigned)(b * 4 + 2 * half) * oplane + (unsigned)(2 * iy) * orow + (unsigned)(2 * (x0 + 1)) * 64u + (unsigned)lane * 16u;
+        q.xlim = iy < H ? W - (x0 + 1) : 0;
+        return q;
+    };
+    auto issue = [&](const Tile& q, int c, int buf) {
+        if (NOMEM & 1) return;
+        const unsigned offc = q.off0 + (unsigned)c * plane_bytes;
+        unsigned char* dst = abuf + buf * TKT::A_BYTES;
+#pragma unroll
+        for (int i = 0; i < TKT::PER_WAVE; ++i) {
+            const int k = wave + 8 * i < TKT::NINST ? wave + 8 * i : wave + 8 * (i - 1);
+            const unsigned off = ((q.okm >> i) & 1u) ? offc + (unsigned)goff[i] : zoff;
+            __builtin_amdgcn_global_load_lds((const SR_AS1 void*)(a.in + off), (SR_AS3 void*)(dst + k * 1024), 16, 0, 0);
+        }
+    };
+    Tile cur = locate(t);
+    issue(cur, 0, 0);
+
+    f32x4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const f32x4*>(a.bias + 32 * half + 8 * g + 4 * h);
+
+    // pixel fragment of shift (dy, dx): halo pixel (wave + 1 - dy, r + 1 - dx), hi unit 2h, lo unit 2h + 1 (swizzled)
+    auto x_addr = [&](int dy, int dx) {
+        const int p = (wave + 1 - dy) * TKT::HC + r + 1 - dx;
+        return p * 64 + (((2 * h) ^ ((p >> 2) & 3)) << 4);
+    };
+    const unsigned char* const bl = wl + lane * 16;
+
+    // Store transpose.  Lane (r, h) holds, for one output row parity and plane, the hi / lo units of output pixels 2r and 2r + 1:
+    // stored from there, one instruction puts 32 bytes into each of 32 different 128-byte lines and a line needs four
+    // instructions -- the write side then takes 0.36 ms alone (micro-benchmark without MFMAs) against 0.19 ms for everything
+    // else.  So the wave passes its 4 KiB (64 records = one contiguous stretch of the output row) through a private LDS
+    // scratch -- logical 16-byte piece P = 8 r + 4 px + 2 h + hl, stored at block P >> 3 with the unit index XORed by the block
+    // number (writes and reads both conflict free) -- and stores piece 64 k + lane in instruction k: 1 KiB contiguous each.
+    unsigned char* const scr = smem + TKT::SCR_OFF + wave * 4096;
+    unsigned sw[4], sr4[4];     // scratch addresses: this lane's four pieces to write, the four pieces it stores
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int unit_w = 4 * (k >> 1) + 2 * h + (k & 1);                 // k = 2 px + hl
+        sw[k] = (unsigned)(r * 128 + ((unit_w ^ (r & 7)) << 4));
+        const int P = 64 * k + lane, blk = P >> 3;
+        sr4[k] = (unsigned)(blk * 128 + (((P & 7) ^ (blk & 7)) << 4));
+    }
+    asm volatile("" : "+v"(sw[0]), "+v"(sw[1]), "+v"(sw[2]), "+v"(sw[3]), "+v"(sr4[0]), "+v"(sr4[1]), "+v"(sr4[2]), "+v"(sr4[3]));
+
+    auto ep_pair = [&](float v0, float v1, u32x4& oh, u32x4& ol, int k) {
+        v0 = fmaxf(v0, 0.f);
+        v1 = fmaxf(v1, 0.f);
+        const unsigned hi = pack_bf16(v0, v1);
+        oh[k] = hi;
+        ol[k] = pack_bf16(v0 - bf_even(hi), v1 - bf_odd(hi));
+    };
+    auto scr_write = [&](int px, const u32x4& oh, const u32x4& ol) {
+        *reinterpret_cast<u32x4*>(scr + sw[2 * px + 0]) = oh;
+        *reinterpret_cast<u32x4*>(scr + sw[2 * px + 1]) = ol;
+    };
+    // the wave's 64 records of output row parity py, plane pl: four contiguous 1 KiB stores
+    auto scr_store = [&](unsigned erow, int xlim, int py, int pl) {
+        const unsigned base = erow + (unsigned)py * orow + (unsigned)pl * oplane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(scr + sr4[k]);
+            const unsigned off = (8 * k + (lane >> 3)) < xlim ? base + (unsigned)k * 1024u : dump;
+            if (!(NOMEM & 4)) *reinterpret_cast<u32x4*>(a.out + off) = v;
+            else asm volatile("" ::"v"(v));
+        }
+    };
+
+    f32x16 acc[4], fin[4];      // by output parity 2 py + px
+    unsigned done_erow = 0;
+    int done_xlim = 0;
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fin[pq][i] = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int q = 0;
+    for (;;) {
+        const int tn = t + npairs;
+        const bool have_next = tn < t_end;
+        Tile nxt;
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[pq][4 * g + j] = bias4[g][j];
+
+        auto plane_step = [&](auto cc) {
+            constexpr int C = decltype(cc)::value;
+            // what drains of the finished tile under this step: output row parity C >> 1, plane C & 1 of the half, both column parities
+            constexpr int PY = C >> 1, PLN = C & 1;
+            if (NOMEM & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // younger: the four stores of the previous step
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (C < 3) {
+                issue(cur, C + 1, (q + 1) & 1);
+            } else {
+                nxt = locate(have_next ? tn : t);
+                issue(nxt, 0, (q + 1) & 1);
+            }
+            const unsigned char* at = abuf + (q & 1) * TKT::A_BYTES;
+            const unsigned char* bw = bl + C * (9 * 2 * 1024);
+            ++q;
+            u32x4 oh0, ol0, oh1, ol1;
+            // tap order: the four taps of shift (0, 0) first (its fragment and tap 0's weights are the only exposed reads), then
+            // shift (0, 1), (1, 0), (1, 1); tap (ky, kx) = shift (ky >> 1, kx >> 1), parity 2 (ky & 1) + (kx & 1)
+            constexpr int order[9] = {0, 1, 3, 4, 2, 5, 6, 7, 8};
+            u32x4 xs[4][2], wf[2][2];
+            auto load_x = [&](int sft) {
+                const int ad = x_addr(sft >> 1, sft & 1);
+                xs[sft][0] = *reinterpret_cast<const u32x4*>(at + ad);
+                xs[sft][1] = *reinterpret_cast<const u32x4*>(at + (ad ^ 16));
+            };
+            auto load_w = [&](int tap, int sb) {
+                wf[sb][0] = *reinterpret_cast<const u32x4*>(bw + (tap * 2 + 0) * 1024);
+                wf[sb][1] = *reinterpret_cast<const u32x4*>(bw + (tap * 2 + 1) * 1024);
+            };
+            if (!(NOMEM & 2)) {
+                load_x(0);
+                load_w(order[0], 0);
+            }
+#pragma unroll
+            for (int n = 0; n < 9; ++n) {
+                const int tap = order[n], ky = tap / 3, kx = tap - 3 * ky;
+                const int sft = (ky >> 1) * 2 + (kx >> 1), par = (ky & 1) * 2 + (kx & 1), sb = n & 1;
+                if (!(NOMEM & 2)) {
+                    if (n + 1 < 9) load_w(order[n + 1], sb ^ 1);
+                    if (n == 0) load_x(1);
+                    if (n == 1) load_x(2);
+                    if (n == 2) load_x(3);
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wf[sb][0]), wlo = __builtin_bit_cast(bf16x8, wf[sb][1]);
+                    const bf16x8 xh = __builtin_bit_cast(bf16x8, xs[sft][0]), xl = __builtin_bit_cast(bf16x8, xs[sft][1]);
+                    acc[par] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[par], 0, 0, 0);
+                    acc[par] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xh, acc[par], 0, 0, 0);
+                    acc[par] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[par], 0, 0, 0);
+                }
+                // epilogue: column parity 0 under taps 0..3 (into the scratch under tap 4), parity 1 under taps 4..7, read back
+                // and stored under tap 8
+                if (n < 4) ep_pair(fin[2 * PY][8 * PLN + 2 * n], fin[2 * PY][8 * PLN + 2 * n + 1], oh0, ol0, n);
+                if (n == 4) scr_write(0, oh0, ol0);
+                if (n >= 4 && n < 8) ep_pair(fin[2 * PY + 1][8 * PLN + 2 * (n - 4)], fin[2 * PY + 1][8 * PLN + 2 * (n - 4) + 1], oh1, ol1, n - 4);
+                if (n == 8) {
+                    scr_write(1, oh1, ol1);
+                    scr_store(done_erow, done_xlim, PY, PLN);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (n + 1 < 9 && k < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (n < 3 && k == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    if (n == 0) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    if (n == 4 && k < 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    if (n == 8 && k == 0) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                    if (n == 8 && k == 1) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    if (n == 0) __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
+                    if (n == 8 && k == 2) __builtin_amdgcn_sched_group_barrier(0x010, 4, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        plane_step(std::integral_constant<int, 0>{});
+        plane_step(std::integral_constant<int, 1>{});
+        plane_step(std::integral_constant<int, 2>{});
+        plane_step(std::integral_constant<int, 3>{});
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) fin[pq] = acc[pq];
+        done_erow = cur.erow;
+        done_xlim = cur.xlim;
+        if (!have_next) break;
+        t = tn;
+        cur = nxt;
+    }
+    // the last tile's epilogue has no MFMAs to hide under
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                u32x4 oh, ol;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ep_pair(fin[2 * py + px][8 * pl + 2 * k], fin[2 * py + px][8 * pl + 2 * k + 1], oh, ol, k);
+                scr_write(px, oh, ol);
+            }
+            scr_store(done_erow, done_xlim, py, pl);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 static int trunk_num_cus() {
     static int n = 0;
     if (!n) {
@@ -360,6 +643,43 @@ static hipError_t launch_trunk_t(const TrunkArgs& a, int grid, hipStream_t s) {
     }
     hipLaunchKernelGGL((trunk_conv_kernel<RELU, RES, NOMEM>), dim3(grid), dim3(512), TK::LDS, s, a);
     return hipGetLastError();
+}
+
+template <int NOMEM>
+static hipError_t launch_trunkT_t(const TrunkArgs& a, int grid, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trunk_convT_kernel<NOMEM>), hipFuncAttributeMaxDynamicSharedMemorySize, TKT::LDS);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((trunk_convT_kernel<NOMEM>), dim3(grid), dim3(512), TKT::LDS, s, a);
+    return hipGetLastError();
+}
+
+// conv2d_transpose_1 on split-planar tensors: a.H, a.W = INPUT size, output 2H x 2W; a.zero_off / a.out_tail = byte offsets of the
+// zero / dump tails behind the input / output tensors
+hipError_t launch_trunk_convT(TrunkArgs a, hipStream_t s) {
+    if (a.B < 1 || a.H < 1 || a.W < 1 || !a.in || !a.out || !a.wpack || !a.bias || a.res || !a.relu) return hipErrorInvalidValue;
+    if ((double)a.B * a.H * a.W * 1024.0 + 4096.0 > 4294967295.0 || (double)a.zero_off + 4096.0 > 4294967295.0 ||
+        (double)a.out_tail + 4096.0 > 4294967295.0)
+        return hipErrorInvalidValue;
+    a.tiles_x = (a.W + TKT::TWX - 1) / TKT::TWX;
+    a.tiles_y = (a.H + TKT::TH - 1) / TKT::TH;
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    const int per_xcd = (ntiles + 7) / 8;
+    int npairs = std::min(std::max(1, trunk_num_cus() / 16), per_xcd);
+    const int rounds = (per_xcd + npairs - 1) / npairs;
+    npairs = (per_xcd + rounds - 1) / rounds;
+    const int grid = 16 * npairs;
+    switch (a.dbg & 7) {
+        case 0: return launch_trunkT_t<0>(a, grid, s);
+        case 1: return launch_trunkT_t<1>(a, grid, s);
+        case 2: return launch_trunkT_t<2>(a, grid, s);
+        case 4: return launch_trunkT_t<4>(a, grid, s);
+        case 5: return launch_trunkT_t<5>(a, grid, s);
+        default: return launch_trunkT_t<7>(a, grid, s);
+    }
 }
 
 hipError_t launch_trunk_conv(TrunkArgs a, hipStream_t s) {

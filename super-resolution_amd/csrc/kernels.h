@@ -74,12 +74,14 @@ struct TrunkArgs {
     const unsigned char* wpack;   // [2 halves][4 chunks][9 taps][hi, lo][64 lanes] x 16 B (sr_api.hip trunk_entries)
     const float* bias;            // [64]
     unsigned zero_off;            // byte offset from `in` of 64 zero bytes (behind the tensor): the source of halo pixels outside the image
+    unsigned out_tail;            // launch_trunk_convT only: byte offset from `out` of the tail behind the (larger) output tensor
     int B, H, W;
     int relu;                     // ReLU after the bias (before the residual)
     int tiles_x, tiles_y;         // set by the launcher
     int dbg;                      // ablation switches for the micro-benchmark (0 in production): 1 no tile DMA, 2 no MFMA loop, 4 no epilogue memory traffic
 };
 hipError_t launch_trunk_conv(TrunkArgs a, hipStream_t s);
+hipError_t launch_trunk_convT(TrunkArgs a, hipStream_t s);   // conv2d_transpose_1, split-planar in and out
 size_t trunk_weight_bytes();
 // channel of k index (half h, element e) inside a 16-channel plane of the split-planar layout
 __host__ __device__ constexpr int split_perm(int h, int e) { return e < 4 ? 4 * h + e : 8 + 4 * h + (e - 4); }

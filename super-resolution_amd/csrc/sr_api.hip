@@ -159,6 +159,24 @@ std::vector<PackEnt> trunk_entries(int cin, int cout) {
     return out;
 }
 
+// conv_trunk.hip trunk_convT_kernel (conv2d_transpose_1): the same fragment layout from a Conv2DTranspose kernel (kh, kw, out, in)
+std::vector<PackEnt> trunkT_entries(int cin, int cout) {
+    std::vector<PackEnt> out;
+    for (int hf = 0; hf < 2; ++hf)
+        for (int c = 0; c < 4; ++c)
+            for (int t = 0; t < 9; ++t)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int j = lane & 31, hh = lane >> 5, co = 32 * hf + j;
+                    const size_t vbase = ((size_t)((hf * 4 + c) * 9 + t) * 2) * 64;
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = 16 * c + split_perm(hh, e);
+                        if (ci < cin && co < cout)
+                            out.push_back({(int32_t)(((size_t)t * cout + co) * cin + ci), (uint32_t)((vbase + lane) * 8 + e)});
+                    }
+                }
+    return out;
+}
+
 // host side of the packing: zero buffer + the listed elements in the arithmetic's storage type
 static std::vector<uint8_t> pack_apply(const std::vector<PackEnt>& ents, size_t bytes, int prec, const float* w) {
     std::vector<uint8_t> out(bytes, 0);
@@ -501,7 +519,7 @@ int run_srnet(sr_ctx* c, int B, float* d_out, bool split) {
             const size_t tail = (size_t)(c->max_batch - c->lane_b0 - b0) * img;
             auto trunk = [&](const ConvLayer& L, const unsigned char* in, unsigned char* out, const unsigned char* res, int relu,
                              const char* name) -> int {
-                TrunkArgs ta = {in, out, res, (const unsigned char*)L.d_w2, L.d_bias, (unsigned)tail, nb, H, W, relu, 0, 0, 0};
+                TrunkArgs ta = {in, out, res, (const unsigned char*)L.d_w2, L.d_bias, (unsigned)tail, 0u, nb, H, W, relu, 0, 0, 0};
                 const double px = (double)nb * H * W;
                 ProfScope ps(c, name, px * 9.0 * L.cin * L.cout * 2.0, px * 256.0 * (res ? 3 : 2) + (double)trunk_weight_bytes());
                 if (tail + 4096 > 4294967295.0) return fail(c, SR_ERR_ARG, "%s: tensor too large for 32-bit offsets", name);
@@ -528,14 +546,33 @@ int run_srnet(sr_ctx* c, int B, float* d_out, bool split) {
         }
     }
     auto b = [&](const char* n) { return lane_buf(c, n); };
-    ConvIO up1 = {b("sx"), H, W, b("up1"), 64, 64, af, nullptr, 0, A_RELU, split ? 1 : c->planar_trunk, 0};
-    up1.in_split = split ? 1 : 0;
-    int rc = run_conv(c, P, st, c->srnet[21], B, up1, "srnet.up1");
-    if (rc) return rc;
+    // split && trunk_up1: conv2d_transpose_1 on conv_trunk.hip's transposed-conv kernel, split-planar in AND out (the input
+    // staging of conv2d_transpose_2 is then a plain copy); SR_NO_TRUNK_UP1=1: the generic transposed-conv kernel, fp32 NHWC out
+    const bool up1_split = split && c->trunk_up1;
+    int rc;
+    if (up1_split) {
+        const ConvLayer& L = c->srnet[21];
+        const size_t left = (size_t)(c->max_batch - c->lane_b0);
+        const size_t tail_in = left * H * W * 256, tail_out = 4 * tail_in;
+        if (tail_out + 4096 > 4294967295.0) return fail(c, SR_ERR_ARG, "srnet.up1: tensor too large for 32-bit offsets");
+        TrunkArgs ta = {(const unsigned char*)b("sx"), (unsigned char*)b("up1"), nullptr, (const unsigned char*)L.d_w2, L.d_bias,
+                        (unsigned)tail_in, (unsigned)tail_out, B, H, W, 1, 0, 0, 0};
+        const double px = (double)B * H * W;
+        ProfScope ps(c, "srnet.up1", px * 9.0 * 64 * 64 * 2.0, px * 256.0 * 5 + (double)trunk_weight_bytes());
+        LAUNCHCHK(c, "srnet.up1", launch_trunk_convT(ta, st));
+    } else {
+        ConvIO up1 = {b("sx"), H, W, b("up1"), 64, 64, af, nullptr, 0, A_RELU, split ? 1 : c->planar_trunk, 0};
+        up1.in_split = split ? 1 : 0;
+        rc = run_conv(c, P, st, c->srnet[21], B, up1, "srnet.up1");
+        if (rc) return rc;
+    }
+    const int u2p = up1_split ? 1 : 0;   // conv2d_transpose_2 reads a split-planar tensor
     if (c->srnet[22].d_proj) {
         // conv2d_transpose_2 + ReLU + the 64 x 27 tap projection of conv2d_36 in one kernel: "up2" holds
         // P[B,4H,4W,32] (128 B per HR pixel instead of 256 B of activations), then the 9-tap gather
-        rc = run_conv(c, P, st, c->srnet[22], B, {b("up1"), 2 * H, 2 * W, b("up2"), 32, 32, 1, nullptr, 0, A_RELU, 0, 0, c->srnet[22].d_proj}, "srnet.up2");
+        ConvIO up2 = {b("up1"), 2 * H, 2 * W, b("up2"), 32, 32, 1, nullptr, 0, A_RELU, u2p, 0, c->srnet[22].d_proj};
+        up2.in_split = u2p;
+        rc = run_conv(c, P, st, c->srnet[22], B, up2, "srnet.up2");
         if (rc) return rc;
         ConvArgs g = {};
         g.in = b("up2");
@@ -555,7 +592,9 @@ int run_srnet(sr_ctx* c, int B, float* d_out, bool split) {
         LAUNCHCHK(c, "srnet.out", launch_tap_gather(g, st));
         return SR_OK;
     }
-    rc = run_conv(c, P, st, c->srnet[22], B, {b("up1"), 2 * H, 2 * W, b("up2"), 64, 64, af, nullptr, 0, A_RELU}, "srnet.up2");
+    ConvIO up2 = {b("up1"), 2 * H, 2 * W, b("up2"), 64, 64, af, nullptr, 0, A_RELU, u2p, 0};
+    up2.in_split = u2p;
+    rc = run_conv(c, P, st, c->srnet[22], B, up2, "srnet.up2");
     if (rc) return rc;
     return run_conv(c, P, st, c->srnet[23], B, {b("up2"), 4 * H, 4 * W, d_out, 3, 3, 1, nullptr, 0, A_CLIP01}, "srnet.out");
 }
@@ -712,6 +751,7 @@ static int create_common(sr_ctx** out, int device, int h_in, int w_in, int ch, i
     if (const char* e = getenv("SR_TRUNK_SUB")) c->trunk_sub = atoi(e);
     if (getenv("SR_NO_PLANAR")) c->planar_trunk = 0;
     c->fuse_pool = getenv("SR_NO_FUSE_POOL") ? 0 : 1;
+    c->trunk_up1 = getenv("SR_NO_TRUNK_UP1") ? 0 : 1;
     if (const char* e = getenv("SR_SPLIT_TRUNK")) c->split_trunk = atoi(e);
     int rc = SR_OK;
     auto bail = [&](int code) {
@@ -877,10 +917,14 @@ int sr_commit_weights(sr_ctx* c) {
         if (rc) return rc;
     }
     if (c->prec == P_BF16X3 && c->split_trunk) {   // split-planar trunk: second packing of the 21 trunk convs and of conv2d_transpose_1
-        for (int i = 0; i <= 21; ++i) {
+        // conv2d_transpose_1: conv_trunk.hip's transposed-conv packing, or (SR_NO_TRUNK_UP1) the generic kernel's with the split
+        // channel order; conv2d_transpose_2: the generic kernel's packing in the split channel order (its input is split-planar
+        // when conv2d_transpose_1 runs on conv_trunk.hip)
+        for (int i = 0; i <= 22; ++i) {
             ConvLayer& L = c->srnet[i];
-            L.ents2 = i < 21 ? trunk_entries(L.cin, L.cout) : pack_entries(L, c->prec, PK_FWD, true);
-            const size_t bytes = i < 21 ? trunk_weight_bytes() : (size_t)L.ncb * L.wstride_cb * 16;
+            const bool tk = i < 21 || (i == 21 && c->trunk_up1);
+            L.ents2 = i < 21 ? trunk_entries(L.cin, L.cout) : (tk ? trunkT_entries(L.cin, L.cout) : pack_entries(L, c->prec, PK_FWD, true));
+            const size_t bytes = tk ? trunk_weight_bytes() : (size_t)L.ncb * L.wstride_cb * 16;
             int rc = upload_alt(c, L, bytes, c->tensors[28 + 2 * i].data.data());
             if (rc) return rc;
         }
@@ -1253,24 +1297,26 @@ int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, in
     if ((rc = upload_layer(nullptr, L, dtype, w.data(), bias.data()))) return rc;
     DevBufs d;
     const size_t npix = (size_t)B * H * W, opix = mode == M_CONV ? npix : 4 * npix;
-    if (getenv("SR_BENCH_TRUNK") && dtype == SR_BF16X3 && !transposed && Cin == 64 && Cout == 64) {
-        // the split-planar trunk kernel (conv_trunk.hip) on random bf16 pairs; ablations via SR_CONV_DBG
-        L.ents2 = trunk_entries(64, 64);
+    if (getenv("SR_BENCH_TRUNK") && dtype == SR_BF16X3 && Cin == 64 && Cout == 64) {
+        // the split-planar trunk kernels (conv_trunk.hip) on random bf16 pairs; ablations via SR_CONV_DBG
+        L.ents2 = transposed ? trunkT_entries(64, 64) : trunk_entries(64, 64);
         if ((rc = upload_alt(nullptr, L, trunk_weight_bytes(), w.data()))) return rc;
-        const size_t bytes = npix * 256;
-        unsigned char* bufs[2] = {(unsigned char*)d.get(bytes + 4096), (unsigned char*)d.get(bytes + 4096)};
+        const size_t bytes = npix * 256, obytes = opix * 256;
+        unsigned char* bufs[2] = {(unsigned char*)d.get(bytes + 4096), (unsigned char*)d.get(obytes + 4096)};
         if (!bufs[0] || !bufs[1]) return fail(nullptr, SR_ERR_HIP, "hipMalloc failed");
         std::vector<uint16_t> hb((bytes + 4096) / 2);
         for (size_t i = 0; i < bytes / 2; ++i) hb[i] = f2bf(rnd() * ((i / 8) & 1 ? 0.004f : 1.f));   // units alternate hi | lo
-        for (int k = 0; k < 2; ++k) HIPCHK(nullptr, hipMemcpy(bufs[k], hb.data(), bytes + 4096, hipMemcpyHostToDevice));
-        TrunkArgs ta = {bufs[0], bufs[1], residual ? bufs[1] : nullptr, (const unsigned char*)L.d_w2, L.d_bias, (unsigned)bytes,
-                        B, H, W, residual ? 0 : 1, 0, 0, g_conv_dbg};
+        HIPCHK(nullptr, hipMemcpy(bufs[0], hb.data(), bytes + 4096, hipMemcpyHostToDevice));
+        if (!transposed) HIPCHK(nullptr, hipMemcpy(bufs[1], hb.data(), bytes + 4096, hipMemcpyHostToDevice));
+        TrunkArgs ta = {bufs[0], bufs[1], residual && !transposed ? bufs[1] : nullptr, (const unsigned char*)L.d_w2, L.d_bias, (unsigned)bytes,
+                        (unsigned)obytes, B, H, W, residual && !transposed ? 0 : 1, 0, 0, g_conv_dbg};
+        auto go = [&]() { return transposed ? launch_trunk_convT(ta, nullptr) : launch_trunk_conv(ta, nullptr); };
         hipEvent_t e0, e1;
         HIPCHK(nullptr, hipEventCreate(&e0));
         HIPCHK(nullptr, hipEventCreate(&e1));
-        for (int i = 0; i < 3; ++i) LAUNCHCHK(nullptr, "trunk", launch_trunk_conv(ta, nullptr));
+        for (int i = 0; i < 3; ++i) LAUNCHCHK(nullptr, "trunk", go());
         HIPCHK(nullptr, hipEventRecord(e0, nullptr));
-        for (int i = 0; i < iters; ++i) LAUNCHCHK(nullptr, "trunk", launch_trunk_conv(ta, nullptr));
+        for (int i = 0; i < iters; ++i) LAUNCHCHK(nullptr, "trunk", go());
         HIPCHK(nullptr, hipEventRecord(e1, nullptr));
         HIPCHK(nullptr, hipEventSynchronize(e1));
         float ms = 0.f;

@@ -96,6 +96,7 @@ struct sr_ctx {
     // 65,536 pixels (small steps are launch bound: the resident-weight kernel reloads 72 KiB per workgroup per launch),
     // 2 = always (SR_SPLIT_TRUNK=2, tests), 0 = never (SR_SPLIT_TRUNK=0)
     int split_trunk = 1;
+    int trunk_up1 = 1;                   // split-planar path: conv2d_transpose_1 on conv_trunk.hip (SR_NO_TRUNK_UP1=1: generic kernel)
     int fuse_pool = 1;                   // FNet: MaxPooling2D in the producing conv's epilogue (SR_NO_FUSE_POOL=1: separate kernel)
     bool step_split = false;   // the step being enqueued uses it
     // two lanes: a step's batch is split into halves that run on `stream` and on `stream2` between a
@@ -135,6 +136,7 @@ int fail(sr_ctx* c, int code, const char* fmt, ...);
 void plan_layer(ConvLayer& L, int prec, int mode, int cin, int cout);
 std::vector<PackEnt> pack_entries(const ConvLayer& L, int prec, int kind, bool kperm = false);
 std::vector<PackEnt> trunk_entries(int cin, int cout);
+std::vector<PackEnt> trunkT_entries(int cin, int cout);
 int upload_alt(sr_ctx* c, ConvLayer& L, size_t bytes, const float* w);   // L.ents2 -> L.d_w2 (bf16x3)
 std::vector<PackEnt> proj_entries(int prec, int cout);
 size_t proj_bytes(int prec);
