@@ -436,7 +436,7 @@ __device__ __forceinline__ void epilogue_proj(const f32x16 (&acc)[G::MT][2], con
             }
         }
     }
-    if (iy < H && ix < W) {
+    if (iy < H && ix < W && !(a.dbg & 256)) {   // dbg 256: ablation of the micro-benchmark, no P stores
         const int oy = 2 * iy + (pass >> 1), ox = 2 * ix + (pass & 1);
         float* op = reinterpret_cast<float*>(a.out) + (((size_t)b * 2 * H + oy) * 2 * W + ox) * 32 + 4 * h;
 #pragma unroll

@@ -1342,6 +1342,14 @@ int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, in
     if (getenv("SR_BENCH_PLANAR") && mode == M_CONV && !L.tapsn && L.steps == prec_maxsteps(dtype, mode) &&
         cout_p == Cout && (Cout * es) % 64 == 0)
         io.in_planar = io.out_planar = 1;   // the SRNet trunk's production layout
+    if (getenv("SR_BENCH_PROJ") && mode == M_CONVT && Cout == 64) {   // the production form of conv2d_transpose_2: fused 64 x 27 tap projection
+        std::vector<float> pw((size_t)9 * 64 * 3);
+        for (auto& v : pw) v = rnd() * 0.1f;
+        if ((rc = upload_proj(nullptr, L, dtype, pw.data(), 3))) return rc;
+        io.out_cs = io.cout_store = 32;
+        io.out_f32 = 1;
+        io.proj_w = L.d_proj;
+    }
     for (int i = 0; i < 3; ++i)
         if ((rc = run_conv(nullptr, dtype, nullptr, L, B, io, "bench_conv"))) return rc;
     if (g_conv_dbg & 64) {
