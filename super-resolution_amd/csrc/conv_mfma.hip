@@ -382,15 +382,11 @@ __device__ __forceinline__ void proj_regs_load(ProjRegs<PREC>& pr, const ConvArg
     }
 }
 
+// the projection itself: p[4 g + j] = P[pixel r][8 g + 4 h + j] of this pass
 template <class G, int PREC>
-__device__ __forceinline__ void epilogue_proj(const f32x16 (&acc)[G::MT][2], const ConvArgs& a, const ProjRegs<PREC>& pr, int pass, int b,
-                                              int y0, int x0, int wave, int lane) {
+__device__ __forceinline__ void proj_compute(const f32x16 (&acc)[G::MT][2], const ConvArgs& a, const ProjRegs<PREC>& pr, f32x16& p) {
     static_assert(G::MT == 1, "transposed-conv tiles have one row per wave");
-    const int r = lane & 31, h = lane >> 5;
-    const int H = a.H, W = a.W;
     const float slope = a.act == A_RELU ? 0.f : (a.act == A_LRELU ? 0.2f : 1.f);
-    const int iy = y0 + wave, ix = x0 + r;
-    f32x16 p;
 #pragma unroll
     for (int i = 0; i < 16; ++i) p[i] = 0.f;
 #pragma unroll
@@ -436,6 +432,16 @@ __device__ __forceinline__ void epilogue_proj(const f32x16 (&acc)[G::MT][2], con
             }
         }
     }
+}
+
+template <class G, int PREC>
+__device__ __forceinline__ void epilogue_proj(const f32x16 (&acc)[G::MT][2], const ConvArgs& a, const ProjRegs<PREC>& pr, int pass, int b,
+                                              int y0, int x0, int wave, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    const int H = a.H, W = a.W;
+    const int iy = y0 + wave, ix = x0 + r;
+    f32x16 p;
+    proj_compute<G, PREC>(acc, a, pr, p);
     if (iy < H && ix < W && !(a.dbg & 256)) {   // dbg 256: ablation of the micro-benchmark, no P stores
         const int oy = 2 * iy + (pass >> 1), ox = 2 * ix + (pass & 1);
         float* op = reinterpret_cast<float*>(a.out) + (((size_t)b * 2 * H + oy) * 2 * W + ox) * 32 + 4 * h;
@@ -1183,6 +1189,10 @@ __global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) 
     __syncthreads();
 
     f32x16 acc[G::MT][2];
+    // fused projection: the four passes' P records are kept and stored at the end of the tile (below), when the workgroup's LDS
+    // (input tile + tap buffers, all free by then) holds four 8 KiB transposition areas: true for the 64-channel layers it is for
+    constexpr bool DEFER = A_BYTES + 2 * TAPV * 16 >= 4 * 8192;
+    f32x16 pk[DEFER ? 4 : 1];
     const unsigned char* bl = smem_b + lane * 16;
     // tap sequence: pass 0 = taps {0,2,6,8}, pass 1 = {1,7}, pass 2 = {3,5}, pass 3 = {4}
     auto tap_iter = [&](auto qc) {
@@ -1219,8 +1229,10 @@ __global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) 
             }
         }
         if (last) {
-            if (a.proj_w) epilogue_proj<G, PREC>(acc, a, pr, pass, b, y0, x0, wave, lane);
-            else epilogue_convt<G>(acc, a, pr.bias4, pass, b, y0, x0, wave, r, h);
+            if (a.proj_w) {
+                if constexpr (DEFER) proj_compute<G, PREC>(acc, a, pr, pk[pass]);
+                else epilogue_proj<G, PREC>(acc, a, pr, pass, b, y0, x0, wave, lane);
+            } else epilogue_convt<G>(acc, a, pr.bias4, pass, b, y0, x0, wave, r, h);
         }
         if (q + 1 < 9) __syncthreads();   // tap q+1 is in LDS for every wave; tap q's buffer is free
     };
@@ -1233,6 +1245,103 @@ __global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) 
     tap_iter(std::integral_constant<int, 6>{});
     tap_iter(std::integral_constant<int, 7>{});
     tap_iter(std::integral_constant<int, 8>{});
+
+    // Fused projection: the P records of the wave's two output rows leave through a per-wave LDS transposition.  A pass holds
+    // the record of pixel r as 16 floats in each of lanes (r, 0) and (r, 1): stored from there, one instruction puts 32 bytes
+    // into each of 32 lines (measured: 0.22 of the layer's 1.31 ms).  Instead the two passes of an output row write their 64
+    // records (8 KiB: the whole row stretch of this tile) into the wave's part of the workgroup's LDS, which nobody reads any more,
+    // and eight instructions store 1 KiB contiguous each.  Records 2 r and 2 r + 1 form one 256-byte LDS row of 16 pieces,
+    // piece slot XOR (r & 15): writes and reads both touch all 64 banks.
+    if constexpr (DEFER) if (a.proj_w && a.gather_out) {
+        // In-kernel tap gather: out[y][x] = act(bias + sum over taps of P[y + ky - 1][x + kx - 1][tap]).  All P records of the 8 x 64
+        // output tile go to LDS (33-float rows: the gather reads one element of 64 different records per instruction), and the
+        // pixels whose nine sources lie in the tile are finished here -- their P never reaches memory (128 B per pixel written,
+        // then read again by tap_gather_kernel: 3.8 GB of the 180p step's traffic).  Border pixels and the ring around the tile get
+        // the partial sum over this tile's records, written to S[k]; gather_fix_kernel adds the (at most four) parts in a fixed order.
+        __syncthreads();        // every wave is done with the input tile and the tap buffers
+        float* const PT = reinterpret_cast<float*>(smem);
+        {
+            const bool in_img = y0 + wave < H && x0 + r < W;   // records outside the image contribute nothing
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                float* rec = PT + (((2 * wave + (pass >> 1)) * 64 + 2 * r + (pass & 1)) * 33 + 4 * h);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (8 * g + j < 23 || (8 * g + j < 27 && h == 0)) rec[8 * g + j] = in_img ? pk[pass][4 * g + j] : 0.f;
+            }
+        }
+        __syncthreads();
+        const int Ho = 2 * H, Wo = 2 * W, oy0 = 2 * y0, ox0 = 2 * x0;
+        const size_t simg = (size_t)a.B * Ho * Wo * 4;
+        float* const S = reinterpret_cast<float*>(a.out);
+        const float hi = a.gather_act == A_CLIP01 ? 1.f : INFINITY;
+        const float lo = a.gather_act == A_NONE ? -INFINITY : 0.f;
+        auto finish = [&](int ly, int lx) {
+            const bool rin = (unsigned)ly < 8u, cin = (unsigned)lx < 64u;
+            const bool inner = ly > 0 && ly < 7 && lx > 0 && lx < 63;
+            float o[3];
+#pragma unroll
+            for (int co = 0; co < 3; ++co) o[co] = inner ? a.gather_bias[co] : 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int sy = ly + ky - 1, sx = lx + kx - 1;
+                    const bool ok = (unsigned)sy < 8u && (unsigned)sx < 64u;
+                    const float* pp = PT + (ok ? (sy * 64 + sx) * 33 : 0) + (ky * 3 + kx) * 3;
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) {
+                        const float v = pp[co];
+                        o[co] += ok ? v : 0.f;
+                    }
+                }
+            const int gy = oy0 + ly, gx = ox0 + lx;
+            if (gy < 0 || gx < 0 || gy >= Ho || gx >= Wo) return;
+            const size_t pix = ((size_t)b * Ho + gy) * Wo + gx;
+            if (inner) {
+                float* op = a.gather_out + pix * a.gather_cs;
+#pragma unroll
+                for (int co = 0; co < 3; ++co)
+                    if (co < a.gather_cout) op[co] = fminf(fmaxf(o[co], lo), hi);
+            } else {
+                const int k = (rin ? 0 : 2) + (cin ? 0 : 1);
+                *reinterpret_cast<f32x4*>(S + k * simg + pix * 4) = f32x4{o[0], o[1], o[2], 0.f};
+            }
+        };
+        finish(tid >> 5, tid & 31);
+        finish(tid >> 5, 32 + (tid & 31));
+        if (tid < 66) finish(-1, tid - 1);                 // the ring around the tile: this tile's part of its neighbours' borders
+        else if (tid < 132) finish(8, tid - 67);
+        else if (tid < 140) finish(tid - 132, -1);
+        else if (tid < 148) finish(tid - 140, 64);
+    } else if (a.proj_w) {
+        __syncthreads();        // every wave is done with the input tile and the tap buffers
+        if (a.dbg & 256) return;   // ablation of the micro-benchmark: no P stores
+        unsigned char* const scr = smem + wave * 8192;
+        const int iy = y0 + wave;
+        const int xlim = 2 * (W - x0);      // records of this tile inside the image
+        unsigned char* const orow0 = reinterpret_cast<unsigned char*>(a.out) + (((size_t)b * 2 * H + 2 * iy) * 2 * W + 2 * x0) * 128;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x16& p = pk[2 * py + px];
+                    const f32x4 o = {p[4 * g], p[4 * g + 1], p[4 * g + 2], p[4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(scr + r * 256 + (((8 * px + 2 * g + h) ^ (r & 15)) << 4)) = o;
+                }
+            unsigned char* const orow = orow0 + (size_t)py * 2 * W * 128;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = 4 * k + (lane >> 4);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * 256 + (((lane & 15) ^ (row & 15)) << 4));
+                if (iy < H && 8 * k + (lane >> 3) < xlim) *reinterpret_cast<f32x4*>(orow + k * 1024 + lane * 16) = v;
+            }
+        }
+    }
 }
 
 size_t conv_lds_bytes(int prec, int mode, int nt, int steps, int mt) {
@@ -1302,10 +1411,18 @@ static hipError_t launch_one(const ConvArgs& a, int ncb, hipStream_t s) {
         if constexpr (NT == 2 && (STEPS * Geo<PREC, MODE, NT, STEPS>::STEPV) % 256 == 0) {
             if (a.nchunk == 1 && !(a.dbg & 128)) {
                 static bool attr2 = false;
-                return launch_k(&convT3x3_lds_kernel<PREC, STEPS>, conv_lds_bytes(PREC, MODE, NT, STEPS, 1), a, 4, ncb, s,
-                                attr2, 0);
+                size_t lds = conv_lds_bytes(PREC, MODE, NT, STEPS, 1);
+                if (a.gather_out) {
+                    // the in-kernel gather exists in the instantiations that keep the four passes' P records (DEFER)
+                    if (lds < 4 * 8192 || !a.proj_w || !a.gather_bias || a.gather_cout > 3 || ncb != 1 ||
+                        (a.gather_act != A_NONE && a.gather_act != A_RELU && a.gather_act != A_CLIP01))
+                        return hipErrorInvalidValue;
+                    lds = std::max(lds, (size_t)GATHER_LDS);
+                }
+                return launch_k(&convT3x3_lds_kernel<PREC, STEPS>, lds, a, 4, ncb, s, attr2, 0);
             }
         }
+        if (a.gather_out) return hipErrorInvalidValue;   // only convT3x3_lds_kernel gathers
         return launch_k(&conv3x3_kernel<PREC, MODE, NT, STEPS>, conv_lds_bytes(PREC, MODE, NT, STEPS, 1), a, 4, ncb,
                         s, attr_done, 0);
     }

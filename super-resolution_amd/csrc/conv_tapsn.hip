@@ -404,6 +404,49 @@ __global__ __launch_bounds__(256, 2) void tap_gather_kernel(const ConvArgs a) {
     }
 }
 
+// Border pixels of the in-kernel gather (conv_mfma.hip convT3x3_lds_kernel, ConvArgs::gather_out): one block per 8 x 64 output
+// tile, one thread per pixel of its outermost ring.  out = act(bias + S0 + S1 + S2 + S3): the tile's own part, then the parts of the
+// horizontal, vertical and diagonal neighbour, where the pixel has them -- a fixed order, so results do not depend on scheduling.
+__global__ __launch_bounds__(192) void gather_fix_kernel(const float* __restrict__ S, float* __restrict__ out, const float* __restrict__ bias,
+                                                         int B, int Ho, int Wo, int tiles_x, int tiles_y, int out_cs, int cout, int act) {
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int slot = threadIdx.x;
+    int ly, lx;
+    if (slot < 64) ly = 0, lx = slot;
+    else if (slot < 128) ly = 7, lx = slot - 64;
+    else if (slot < 134) ly = slot - 127, lx = 0;
+    else if (slot < 140) ly = slot - 133, lx = 63;
+    else return;
+    const int gy = 8 * ty + ly, gx = 64 * tx + lx;
+    if (gy >= Ho || gx >= Wo) return;
+    const bool hz = (lx == 0 && gx > 0) || (lx == 63 && gx + 1 < Wo);
+    const bool vt = (ly == 0 && gy > 0) || (ly == 7 && gy + 1 < Ho);
+    const size_t simg = (size_t)B * Ho * Wo * 4;
+    const size_t pix = ((size_t)b * Ho + gy) * Wo + gx;
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(S + pix * 4);
+    float o[3] = {bias[0] + s0[0], bias[1] + s0[1], bias[2] + s0[2]};
+    if (hz) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(S + simg + pix * 4);
+        o[0] += v[0], o[1] += v[1], o[2] += v[2];
+    }
+    if (vt) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(S + 2 * simg + pix * 4);
+        o[0] += v[0], o[1] += v[1], o[2] += v[2];
+    }
+    if (hz && vt) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(S + 3 * simg + pix * 4);
+        o[0] += v[0], o[1] += v[1], o[2] += v[2];
+    }
+    float* op = out + pix * out_cs;
+#pragma unroll
+    for (int co = 0; co < 3; ++co)
+        if (co < cout) op[co] = act_t(o[co], act);
+}
+
 int cu_count() {
     static int n = 0;
     if (!n) {
@@ -449,6 +492,17 @@ hipError_t launch_tap_gather(const ConvArgs& a, hipStream_t s) {
     const int rounds = (per_xcd + max_slots - 1) / max_slots;
     const int slots = (per_xcd + rounds - 1) / rounds;
     hipLaunchKernelGGL(tap_gather_kernel, dim3(8 * slots), dim3(256), T::P_BYTES, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_fix(const ConvArgs& a, hipStream_t s) {
+    if (!a.gather_out || !a.gather_bias || a.gather_cout > 3) return hipErrorInvalidValue;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + 3) / 4;   // the transposed conv's tiles: 4 x 32 input pixels
+    const long n = (long)tiles_x * tiles_y * a.B;
+    if (n <= 0) return hipSuccess;
+    if (n > 0x7fffffffL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_fix_kernel, dim3((unsigned)n), dim3(192), 0, s, reinterpret_cast<const float*>(a.out), a.gather_out,
+                       a.gather_bias, a.B, 2 * a.H, 2 * a.W, tiles_x, tiles_y, a.gather_cs, a.gather_cout, a.gather_act);
     return hipGetLastError();
 }
 

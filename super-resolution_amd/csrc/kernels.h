@@ -51,6 +51,13 @@ struct ConvArgs {
     // [B,H/2,W/2,out_cs] here (H, W even; `out` is not written).  FNet's encoder: Conv2D + LeakyReLU + MaxPooling2D,
     // reference layers.py:31-36 -- the full-resolution tensor has no other reader.
     void* pool_out;
+    // transposed conv with proj_w: add the nine shifted taps in the kernel as well (conv_mfma.hip, end of convT3x3_lds_kernel).
+    // gather_out [B,2H,2W,gather_cs] receives act(bias + sum) of every pixel whose 3x3 neighbourhood lies inside the workgroup's
+    // 8 x 64 output tile; for the pixels on a tile's border, `out` takes four partial-sum images S[k][B][2H][2W][4 floats]
+    // (k = 2 * (from the tile above/below) + (from the tile left/right)) that launch_gather_fix adds up.  nullptr: out = P
+    float* gather_out;
+    const float* gather_bias;   // [3], the gathered conv's bias
+    int gather_cs, gather_cout, gather_act;   // pixel stride / stored channels (<= 3) / A_NONE, A_RELU or A_CLIP01
 };
 
 // steps per chunk / chunk geometry, shared by the packer and the kernel
@@ -91,6 +98,9 @@ hipError_t launch_conv(int prec, int mode, int nt, int steps, const ConvArgs& a,
 hipError_t launch_conv_tapsn(int prec, int nchunk, const ConvArgs& a, hipStream_t s);
 // out[y,x,co] = act(bias[co] + sum_tap P[y+ky-1, x+kx-1][tap*3+co]) (+ residual); a.in = P [B,H,W,32] fp32
 hipError_t launch_tap_gather(const ConvArgs& a, hipStream_t s);
+// finishes the tile-border pixels of an in-kernel gather (ConvArgs::gather_out): a = the transposed conv's arguments
+hipError_t launch_gather_fix(const ConvArgs& a, hipStream_t s);
+constexpr int GATHER_LDS = 8 * 64 * 33 * 4;   // the P records of one 8 x 64 output tile, 33-float rows
 size_t conv_lds_bytes(int prec, int mode, int nt, int steps, int mt);
 
 // element-wise / gather kernels (fused_ops.hip).  act_bf16: activations are bf16.

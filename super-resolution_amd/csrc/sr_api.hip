@@ -310,7 +310,7 @@ void prof_resolve(sr_ctx* c) {
 // ---------------------------------------------------------------- layer launch
 
 int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, const ConvIO& io, const char* name) {
-    ConvArgs a;
+    ConvArgs a = {};
     a.in = io.in;
     a.wpack = L.d_w;
     a.bias = L.d_bias;
@@ -331,6 +331,13 @@ int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, con
     a.res_mask = io.res_mask;
     a.in_split = io.in_split;
     a.pool_out = io.pool_out;
+    a.gather_out = io.gather_out;
+    a.gather_bias = io.gather_bias;
+    a.gather_cs = io.gather_cs;
+    a.gather_cout = io.gather_cout;
+    a.gather_act = io.gather_act;
+    if (io.gather_out && (!io.proj_w || !io.gather_bias || io.gather_cout < 1 || io.gather_cout > 3 || io.gather_cs < io.gather_cout))
+        return fail(c, SR_ERR_ARG, "%s: the in-kernel tap gather needs the tap projection and a bias of <= 3 channels", name);
     if (io.pool_out && (L.tapsn || L.mode != M_CONV || io.res || io.out_planar || io.res_mask || (io.H & 1) || (io.W & 1) ||
                         (io.cout_store * (io.out_f32 ? 4 : 2)) % 16 || (io.out_cs * (io.out_f32 ? 4 : 2)) % 16))
         return fail(c, SR_ERR_ARG, "%s: the fused max pooling needs a plain 3x3 conv on an even-sized image with vector-aligned channels", name);
@@ -361,11 +368,17 @@ int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, con
     const double esz_in = prec == P_BF16 ? 2 : 4, esz_out = io.out_f32 ? 4 : 2;
     const double opx = L.mode == M_CONV ? px : 4 * px;
     const double flops = px * 9.0 * L.cin * L.cout * 2.0;
-    const double bytes = px * L.cin * esz_in + opx * io.cout_store * esz_out * (io.res ? 2 : 1) + L.wbytes;
+    // in-kernel gather: the image itself + the partial sums of the 8 x 64 tiles' border rings (written, then read by the fix kernel)
+    const double out_px_bytes = io.gather_out ? io.gather_cout * 4.0 + 2.0 * 16.0 * (140 + 148) / 512.0
+                                              : io.cout_store * esz_out * (io.res ? 2 : 1);
+    const double bytes = px * L.cin * esz_in + opx * out_px_bytes + L.wbytes;
     hipError_t e;
     if (L.tapsn && (!io.out_f32 || io.cout_store > 3)) return fail(c, SR_ERR_ARG, "%s: taps-in-N conv needs an fp32 output of <= 3 channels", name);
     auto launch = [&]() {
-        return L.tapsn ? launch_conv_tapsn(prec, L.nchunk, a, st) : launch_conv(prec, L.mode, L.nt, L.steps, a, L.ncb, st);
+        if (L.tapsn) return launch_conv_tapsn(prec, L.nchunk, a, st);
+        hipError_t le = launch_conv(prec, L.mode, L.nt, L.steps, a, L.ncb, st);
+        if (le == hipSuccess && a.gather_out) le = launch_gather_fix(a, st);   // the tile-border pixels
+        return le;
     };
     if (c) {
         ProfScope ps(c, name, flops, bytes);
@@ -568,10 +581,20 @@ int run_srnet(sr_ctx* c, int B, float* d_out, bool split) {
     }
     const int u2p = up1_split ? 1 : 0;   // conv2d_transpose_2 reads a split-planar tensor
     if (c->srnet[22].d_proj) {
-        // conv2d_transpose_2 + ReLU + the 64 x 27 tap projection of conv2d_36 in one kernel: "up2" holds
-        // P[B,4H,4W,32] (128 B per HR pixel instead of 256 B of activations), then the 9-tap gather
+        // conv2d_transpose_2 + ReLU + the 64 x 27 tap projection of conv2d_36 in one kernel ...
         ConvIO up2 = {b("up1"), 2 * H, 2 * W, b("up2"), 32, 32, 1, nullptr, 0, A_RELU, u2p, 0, c->srnet[22].d_proj};
         up2.in_split = u2p;
+        if (c->fuse_gather) {
+            // ... and conv2d_36's nine-tap sum + clip as well: the kernel writes the image, except the tile-border pixels, whose
+            // partial sums ("up2": 4 x 16 B per HR pixel, sparsely written) a small second kernel adds (ConvArgs::gather_out)
+            up2.gather_out = d_out;
+            up2.gather_bias = c->srnet[23].d_bias;
+            up2.gather_cs = 3;
+            up2.gather_cout = 3;
+            up2.gather_act = A_CLIP01;
+            return run_conv(c, P, st, c->srnet[22], B, up2, "srnet.up2");
+        }
+        // SR_NO_FUSE_GATHER=1: "up2" holds P[B,4H,4W,32] (128 B per HR pixel instead of 256 B of activations), then the 9-tap gather
         rc = run_conv(c, P, st, c->srnet[22], B, up2, "srnet.up2");
         if (rc) return rc;
         ConvArgs g = {};
@@ -751,6 +774,7 @@ static int create_common(sr_ctx** out, int device, int h_in, int w_in, int ch, i
     if (const char* e = getenv("SR_TRUNK_SUB")) c->trunk_sub = atoi(e);
     if (getenv("SR_NO_PLANAR")) c->planar_trunk = 0;
     c->fuse_pool = getenv("SR_NO_FUSE_POOL") ? 0 : 1;
+    c->fuse_gather = getenv("SR_NO_FUSE_GATHER") ? 0 : 1;
     c->trunk_up1 = getenv("SR_NO_TRUNK_UP1") ? 0 : 1;
     if (const char* e = getenv("SR_SPLIT_TRUNK")) c->split_trunk = atoi(e);
     int rc = SR_OK;

@@ -97,6 +97,7 @@ struct sr_ctx {
     // 2 = always (SR_SPLIT_TRUNK=2, tests), 0 = never (SR_SPLIT_TRUNK=0)
     int split_trunk = 1;
     int trunk_up1 = 1;                   // split-planar path: conv2d_transpose_1 on conv_trunk.hip (SR_NO_TRUNK_UP1=1: generic kernel)
+    int fuse_gather = 1;                 // SRNet tail: conv2d_36's tap sum inside conv2d_transpose_2's kernel (SR_NO_FUSE_GATHER=1: tap_gather_kernel)
     int fuse_pool = 1;                   // FNet: MaxPooling2D in the producing conv's epilogue (SR_NO_FUSE_POOL=1: separate kernel)
     bool step_split = false;   // the step being enqueued uses it
     // two lanes: a step's batch is split into halves that run on `stream` and on `stream2` between a
@@ -186,6 +187,11 @@ struct ConvIO {
     int in_split = 0;                    // transposed conv, bf16x3: planar input is split-planar; uses the layer's d_w2
     int res_mask = 0;                    // kernels.h ConvArgs::res_mask: res is the activation output to mask by
     void* pool_out = nullptr;            // kernels.h ConvArgs::pool_out: store the 2x2 max pooling of the output here instead
+    // kernels.h ConvArgs::gather_out: with proj_w, also gather the taps in the kernel; out = the partial-sum images, and a
+    // launch_gather_fix follows inside run_conv
+    float* gather_out = nullptr;
+    const float* gather_bias = nullptr;
+    int gather_cs = 0, gather_cout = 0, gather_act = 0;
 };
 
 int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, const ConvIO& io, const char* name);

@@ -86,11 +86,12 @@ def test_step_vs_oracle_fp32(sh, weights7, h, w, B):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
-@pytest.mark.parametrize("env", ["SR_NO_PLANAR", "SR_NO_FUSE_OUT", "SR_NO_TAPSN", "SR_NO_FUSE_POOL"])
+@pytest.mark.parametrize("env", ["SR_NO_PLANAR", "SR_NO_FUSE_OUT", "SR_NO_TAPSN", "SR_NO_FUSE_POOL", "SR_NO_FUSE_GATHER"])
 def test_layout_switches_keep_parity(sh, weights7, env, dtype):
     """The A/B switches (NHWC trunk instead of 64-byte planes; unfused transposed conv + 64->3 conv;
     generic kernel for the <=3-channel convs; FNet's max pooling as a kernel of its own instead of inside the
-    producing conv's epilogue) select older kernels of the same path: same bar."""
+    producing conv's epilogue; conv2d_36's tap sum as a kernel of its own instead of at the end of conv2d_transpose_2's)
+    select older kernels of the same path: same bar."""
     lr_t, lr_tm1, est = step_inputs(300, 2, 24, 40)
     want, want_lw = rt.generator_step(weights7, lr_t, lr_tm1, est)
     os.environ[env] = "1"
@@ -128,6 +129,35 @@ def test_fused_max_pooling_is_the_pooling_kernel(sh, weights7, B, h, w, dtype):
     if dtype != "bf16":
         want = rt.to_nhwc(rt.fnet(rt.TorchWeights(weights7), rt.to_nchw(lr_t), rt.to_nchw(lr_tm1)))
         assert np.abs(flows[0] - want).max() <= FP32_TOL
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("B,h,w", [(2, 24, 40), (1, 8, 72), (3, 16, 8), (1, 96, 144), (1, 8, 8), (1, 8, 16)])
+def test_in_kernel_tap_gather_is_the_gather_kernel(sh, weights7, B, h, w, dtype):
+    """conv2d_36's nine-tap sum inside conv2d_transpose_2's kernel against tap_gather_kernel on the stored P tensor.  Pixels
+    whose 3x3 neighbourhood lies in one 8 x 64 output tile add bias and taps in the same order: bit for bit.  Pixels on a tile
+    border add the per-tile partial sums instead (own, horizontal, vertical, diagonal): a different association of the same
+    ten fp32 terms, a few ulp.  LR sizes are multiples of 8, so rows always fill the 8-row tiles; 4w = 32, 160, 288 and 576 columns
+    leave half a 64-column tile at the right edge, 4w = 64 is exactly one tile column."""
+    lr_t, lr_tm1, est = step_inputs(330 + h, B, h, w)
+    outs = []
+    for off in (False, True):
+        if off:
+            os.environ["SR_NO_FUSE_GATHER"] = "1"
+        try:
+            ctx = make_ctx(sh, weights7, h, w, B, dtype=dtype)
+            outs.append(ctx.step(lr_t, lr_tm1, est)[0])
+            ctx.close()
+        finally:
+            os.environ.pop("SR_NO_FUSE_GATHER", None)
+    fused, separate = outs
+    H, W = 4 * h, 4 * w
+    ys, xs = np.arange(H) % 8, np.arange(W) % 64
+    inner = ((ys > 0) & (ys < 7) & (np.arange(H) < H - 1))[:, None] & ((xs > 0) & (xs < 63) & (np.arange(W) < W - 1))[None, :]
+    # (the last image row / column is interior to its tile when the tile is ragged; its missing taps are exact zeros either way,
+    # but keep the bit-exact claim to pixels with nine real sources)
+    assert np.array_equal(fused[:, inner], separate[:, inner])
+    assert np.abs(fused - separate).max() <= 2e-6
 
 
 def test_golden_clip24x40(sh, weights7):
