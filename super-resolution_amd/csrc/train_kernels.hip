@@ -675,13 +675,34 @@ template <int COUT>   // compile-time: the wave's 16 x COUT weights of a tap are
 __global__ __launch_bounds__(256) void dgrad_few_kernel(const float* __restrict__ g, const float* __restrict__ w,
                                                         float* __restrict__ dx, const float* __restrict__ y, int act,
                                                         int B, int H, int W, int cin, int gcs, int xcs) {
+    // the workgroup's 64 pixels x cin channels, transposed on the way in (the activation output y) and out (dX): a lane owns 64
+    // bytes of its pixel, so from registers one instruction would touch 16 bytes of each of 64 lines (measured: 1.44 GB written
+    // for a 671 MB tensor); through LDS every instruction moves whole lines
+    __shared__ __attribute__((aligned(16))) unsigned char tile[64 * 256];
     const int lane = threadIdx.x & 63;
-    const int c0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c0 = wv * 16;
     const long npix = (long)B * H * W;
-    const long p = (long)blockIdx.x * 64 + lane;
-    if (p >= npix) return;
-    const int x = p % W;
-    const int yy = (p / W) % H;
+    const long p0 = (long)blockIdx.x * 64;
+    const long p = p0 + lane;
+    const bool live = p < npix;
+    const long pc = live ? p : npix - 1;
+    const int x = pc % W;
+    const int yy = (pc / W) % H;
+    // LDS row = pixel (cin * 4 bytes), 16-byte pieces XOR-swizzled by the pixel so that the 64 lanes of an access spread over the banks
+    const int row_bytes = cin * 4, pieces = cin >> 2;            // pieces per pixel: 4, 8, 12 or 16
+    const int sm = pieces == 16 ? 15 : (pieces == 8 ? 7 : 3);    // the XOR stays inside the row
+    // piece 64 * (cin / 16) * k + thread of the tile (k < 4): the tile is contiguous in memory when xcs == cin
+    int prow[4], ppc[4];
+    f32x4 mreg[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int P = k * (int)blockDim.x + (int)threadIdx.x;
+        prow[k] = P / pieces;
+        ppc[k] = P - prow[k] * pieces;
+        mreg[k] = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (y && p0 + prow[k] < npix) mreg[k] = *reinterpret_cast<const f32x4*>(y + (p0 + prow[k]) * xcs + 4 * ppc[k]);   // lands under the FMAs
+    }
     float acc[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) acc[c] = 0.f;
@@ -689,7 +710,7 @@ __global__ __launch_bounds__(256) void dgrad_few_kernel(const float* __restrict_
     for (int tap = 0; tap < 9; ++tap) {
         const int sy = yy + 1 - tap / 3, sx = x + 1 - tap % 3;
         const bool in = sy >= 0 && sy < H && sx >= 0 && sx < W;
-        const f32x4 u = *reinterpret_cast<const f32x4*>(g + (in ? (p + (1 - tap / 3) * W + (1 - tap % 3)) * gcs : 0));
+        const f32x4 u = *reinterpret_cast<const f32x4*>(g + (in ? (pc + (1 - tap / 3) * W + (1 - tap % 3)) * gcs : 0));
         const float* wt = w + ((size_t)tap * cin + c0) * COUT;   // wave-uniform: scalar loads
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
@@ -698,19 +719,31 @@ __global__ __launch_bounds__(256) void dgrad_few_kernel(const float* __restrict_
             for (int c = 0; c < 16; ++c) acc[c] += gv * wt[c * COUT + co];
         }
     }
-    float* o = dx + p * xcs + c0;
-    const float* ym = y ? y + p * xcs + c0 : nullptr;
     const float neg = act == A_LRELU ? 0.2f : 0.f;
+    if (y) {   // the activation output of the tile, read in full lines above, to the lanes that own it
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            *reinterpret_cast<f32x4*>(tile + prow[k] * row_bytes + ((ppc[k] ^ (prow[k] & sm)) << 4)) = mreg[k];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mreg[q] = *reinterpret_cast<const f32x4*>(tile + lane * row_bytes + (((4 * wv + q) ^ (lane & sm)) << 4));
+        __syncthreads();
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-        if (ym) {
-            const f32x4 m = *reinterpret_cast<const f32x4*>(ym + 4 * q);
+        if (y) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= m[e] > 0.f ? 1.f : neg;
+            for (int e = 0; e < 4; ++e) v[e] *= mreg[q][e] > 0.f ? 1.f : neg;
         }
-        *reinterpret_cast<f32x4*>(o + 4 * q) = v;
+        *reinterpret_cast<f32x4*>(tile + lane * row_bytes + (((4 * wv + q) ^ (lane & sm)) << 4)) = v;
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (p0 + prow[k] < npix)
+            *reinterpret_cast<f32x4*>(dx + (p0 + prow[k]) * xcs + 4 * ppc[k]) =
+                *reinterpret_cast<const f32x4*>(tile + prow[k] * row_bytes + ((ppc[k] ^ (prow[k] & sm)) << 4));
 }
 
 // cin 16 .. 64 in steps of 16, cout <= 3, gcs and xcs multiples of 4 (dY rows are read 16 bytes at a time, so the

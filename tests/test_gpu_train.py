@@ -342,10 +342,12 @@ def test_train_on_clips_equals_the_host_built_batch(sh, weights7, dtype, model):
         got_g = np.empty(ctx.param_count(), np.float32)
         assert sh.lib().sr_train_read_grads(ctx._h, got_g.ctypes.data_as(C.c_void_p)) == 0
         assert np.allclose(got_l, want_l, rtol=1e-5), (got_l, want_l)
-        # fp32: same per-sample arithmetic up to summation order.  bf16x3: the library takes the previous estimates
-        # from its taped training forward (unfused x4 tail), the host-built batch from step() (fused tail): two
-        # bf16x3 evaluations of the same function, ~4e-5 apart, and the gradients follow (measured 1.1e-4)
-        assert rel_err(got_g, want_g) <= (2e-5 if dtype == "fp32" else 1e-3), rel_err(got_g, want_g)
+        # The library takes the previous estimates from its taped training forward (unfused x4 tail), the host-built
+        # batch from step() (fused tail: conv2d_36's taps are summed per 8 x 64 tile, another association of the same
+        # fp32 terms on tile-border pixels; in bf16x3 two evaluations ~4e-5 apart).  The estimates differ by ulps,
+        # the clip / ReLU masks of these noise frames flip at a few pixels, and the gradients follow: measured 2.3e-4
+        # (fp32; within 2e-5 with SR_NO_FUSE_GATHER=1, the identical arithmetic) and 1.1e-4 (bf16x3)
+        assert rel_err(got_g, want_g) <= 1e-3, rel_err(got_g, want_g)
     # the Adam variant moves the weights like train_on_batch on the host-built batch
     ctx2 = sh.Context(h, w, max_batch=n * c, dtype=dtype, model=model)
     ctx2.load_weights(weights7)
