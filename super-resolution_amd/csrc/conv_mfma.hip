@@ -1165,15 +1165,15 @@ __global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) 
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpack) + (size_t)blockIdx.y * a.wstride_cb + tid;
     const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * H * W * a.cin_p * G::ESZ;
 
-    u32x4 regs_w[WIT];
-    auto load_tap = [&](int q) {   // taps are packed in consumption order: pass major, tap, step, n, hi/lo, lane
-#pragma unroll
-        for (int it = 0; it < WIT; ++it) regs_w[it] = wsrc[(size_t)q * TAPV + it * 256];
-    };
-    auto store_tap = [&](int buf) {
+    // A tap's weights go global -> LDS by DMA (global_load_lds_dwordx4: no registers, no ds_write): tap q + 1 is requested at the
+    // start of tap q into the buffer tap q - 1 was read from, and awaited (vmcnt(0): nothing else is in flight in the tap loop)
+    // before the barrier that ends tap q.  Taps are packed in consumption order: pass major, tap, step, n, hi/lo, lane.
+    auto dma_tap = [&](int q) {
+        unsigned char* dst = smem_b + (size_t)(q & 1) * TAPV * 16 + wave * 1024;
 #pragma unroll
         for (int it = 0; it < WIT; ++it)
-            *reinterpret_cast<u32x4*>(smem_b + (size_t)buf * TAPV * 16 + (it * 256 + tid) * 16) = regs_w[it];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)q * TAPV + it * 256),
+                                             (__attribute__((address_space(3))) void*)(dst + it * 4096), 16, 0, 0);
     };
     ProjRegs<PREC> pr;
     proj_regs_load<G, PREC>(pr, a, lane);
@@ -1181,11 +1181,10 @@ __global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) 
     {
         u32x4 regs[G::ITER];
         stage_load<G, PREC>(regs, inb, 0, a.cin_p, y0, x0, H, W, tid, a.in_planar, a.in_planar);
-        load_tap(0);
+        dma_tap(0);
         stage_store<G, PREC>(regs, smem, tid, a.in_split, a.in_planar);
     }
-    store_tap(0);
-    load_tap(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     f32x16 acc[G::MT][2];
@@ -1201,8 +1200,7 @@ __global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) 
         constexpr int tidx = q < 4 ? q : (q < 6 ? q - 4 : (q < 8 ? q - 6 : 0));
         constexpr int tap = pass_tap(M_CONVT, pass, tidx);
         constexpr bool first = tidx == 0, last = tidx + 1 == pass_ntaps(M_CONVT, pass);
-        if (q + 1 < 9) store_tap((q + 1) & 1);   // its previous contents (tap q-1) were released by the last barrier
-        if (q + 2 < 9) load_tap(q + 2);          // lands during this tap's MFMAs
+        if (q + 1 < 9) dma_tap(q + 1);           // that buffer's previous contents (tap q-1) were released by the last barrier
         if (first) zero_acc<G, 2>(acc);
         const unsigned char* bq = bl + (size_t)(q & 1) * TAPV * 16;
         u32x4 fa[2][G::MT][G::AV], fb[2][NB];
@@ -1234,7 +1232,10 @@ __global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) 
                 else epilogue_proj<G, PREC>(acc, a, pr, pass, b, y0, x0, wave, lane);
             } else epilogue_convt<G>(acc, a, pr.bias4, pass, b, y0, x0, wave, r, h);
         }
-        if (q + 1 < 9) __syncthreads();   // tap q+1 is in LDS for every wave; tap q's buffer is free
+        if (q + 1 < 9) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of tap q+1 has landed
+            __syncthreads();                                   // tap q+1 is in LDS for every wave; tap q's buffer is free
+        }
     };
     tap_iter(std::integral_constant<int, 0>{});
     tap_iter(std::integral_constant<int, 1>{});
