@@ -1260,8 +1260,9 @@ __global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) 
         // then read again by tap_gather_kernel: 3.8 GB of the 180p step's traffic).  Border pixels and the ring around the tile get
         // the partial sum over this tile's records, written to S[k]; gather_fix_kernel adds the (at most four) parts in a fixed order.
         __syncthreads();        // every wave is done with the input tile and the tap buffers
+        if (a.dbg & 256) return;   // ablations of the micro-benchmark: 256 no gather phase, 512 no record writes, 1024 no global stores
         float* const PT = reinterpret_cast<float*>(smem);
-        {
+        if (!(a.dbg & 512)) {
             const bool in_img = y0 + wave < H && x0 + r < W;   // records outside the image contribute nothing
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
@@ -1301,6 +1302,10 @@ __global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) 
             const int gy = oy0 + ly, gx = ox0 + lx;
             if (gy < 0 || gx < 0 || gy >= Ho || gx >= Wo) return;
             const size_t pix = ((size_t)b * Ho + gy) * Wo + gx;
+            if (a.dbg & 1024) {
+                asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]));
+                return;
+            }
             if (inner) {
                 float* op = a.gather_out + pix * a.gather_cs;
 #pragma unroll

@@ -1373,6 +1373,13 @@ int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, in
         io.out_cs = io.cout_store = 32;
         io.out_f32 = 1;
         io.proj_w = L.d_proj;
+        if (getenv("SR_BENCH_GATHER")) {   // ... and the in-kernel tap sum: image out, d_out takes the border partial sums
+            io.gather_out = (float*)d.get(opix * 3 * 4);
+            if (!io.gather_out) return fail(nullptr, SR_ERR_HIP, "hipMalloc failed");
+            io.gather_bias = L.d_bias;
+            io.gather_cs = io.gather_cout = 3;
+            io.gather_act = A_CLIP01;
+        }
     }
     for (int i = 0; i < 3; ++i)
         if ((rc = run_conv(nullptr, dtype, nullptr, L, B, io, "bench_conv"))) return rc;
