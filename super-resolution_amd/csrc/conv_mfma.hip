@@ -1178,7 +1178,9 @@ __global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) 
     ProjRegs<PREC> pr;
     proj_regs_load<G, PREC>(pr, a, lane);
 
-    {
+    if (a.dbg & 2048) {   // ablation of the micro-benchmark: no input staging (what a perfectly hidden prologue would cost)
+        dma_tap(0);
+    } else {
         u32x4 regs[G::ITER];
         stage_load<G, PREC>(regs, inb, 0, a.cin_p, y0, x0, H, W, tid, a.in_planar, a.in_planar);
         dma_tap(0);
@@ -1350,6 +1352,261 @@ __global__ __launch_bounds__(256, 2) void convT3x3_lds_kernel(const ConvArgs a) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv2d_transpose_2 + tap projection + in-kernel tap sum as a PERSISTENT kernel (bf16x3, split-planar input; the production
+// form of SRNet's x4 tail).  convT3x3_lds_kernel spends a quarter of its time on the input tile: 47.5 KiB fetched, written to
+// LDS and awaited before the first MFMA of every workgroup (micro-benchmark: 1.22 ms, 0.94 ms with the staging removed).  Here a
+// workgroup walks tiles blockIdx.x, + gridDim.x, ...: the next tile's input is requested into registers at tap 7 (inline-asm
+// loads, issued AFTER the last weight-tap DMA so that the counted wait for that tap does not include them), lands under taps 7, 8,
+// the projection and is written to LDS after the gather phase; the next tile's first weight tap is DMAed at tap 8 into the tap
+// buffer that is free by then.  LDS map: [tap buffer 0][input tile][tap buffer 1]; a tile with parity p reads tap q from buffer
+// (q + p) & 1, its gather records (29-float rows, 58 KiB) take the input tile plus the buffer its own tap 8 was in -- the other
+// buffer already holds the next tile's tap 0 -- and the next tile runs with the opposite parity.
+template <int PREC, int STEPS>
+__global__ __launch_bounds__(256, 2) void convT3x3_gather_kernel(const ConvArgs a) {
+    using G = Geo<PREC, M_CONVT, 2, STEPS>;
+    static_assert(PREC == P_BF16X3, "split-planar input");
+    constexpr int NB = 2 * G::BV;
+    constexpr int TAPV = STEPS * G::STEPV;
+    static_assert(TAPV % 256 == 0, "a tap's weights split evenly over the workgroup");
+    constexpr int WIT = TAPV / 256;
+    constexpr int TAPB = TAPV * 16;
+    constexpr int A_BYTES = G::TILE_BYTES * G::AV;
+    constexpr int PTS = 29;                          // floats per gather record (27 used; odd: conflict-free column reads)
+    static_assert(8 * 64 * PTS * 4 <= TAPB + A_BYTES, "the gather records fit in the input tile plus one tap buffer");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const smem_a = smem + TAPB;
+
+    // raw barriers with hand-placed waits: __syncthreads() makes hipcc wait vmcnt(0), which would drain the prefetch at tap 7
+    auto bar = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    const int H = a.H, W = a.W;
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    ProjRegs<PREC> pr;
+    proj_regs_load<G, PREC>(pr, a, threadIdx.x & 63);
+    const size_t img_bytes = (size_t)H * W * a.cin_p * G::ESZ;
+    const unsigned plane_bytes = (unsigned)(H * W * 64);
+    struct TileXY {
+        int b, y0, x0;
+    };
+    auto decode = [&](int tt) {
+        TileXY q;
+        const int txi = tt % a.tiles_x;
+        tt /= a.tiles_x;
+        q.y0 = (tt % a.tiles_y) * G::TH;
+        q.b = tt / a.tiles_y;
+        q.x0 = txi * TW;
+        return q;
+    };
+    // the input tile of tile q into registers: vector v = tid + 256 it is unit (v & 3) of halo pixel (v % (4 NPIX)) >> 2 of plane
+    // v / (4 NPIX); lanes without a source (outside the image, past the tile) load the image's first bytes and are zeroed on
+    // the way to LDS.  Inline asm: ordinary loads could be scheduled across the DMA the counted waits rely on.
+    u32x4 regs_n[G::ITER];
+    unsigned okm = 0;
+    auto prefetch = [&](const TileXY& q, int tid) {
+        const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in) + (size_t)q.b * img_bytes;
+        okm = 0;
+#pragma unroll
+        for (int it = 0; it < G::ITER; ++it) {
+            const int v = tid + it * 256;
+            int p, part;
+            vec_map<G>(v, 1, p, part);
+            const int py = p / G::HCOLS, px = p - py * G::HCOLS;
+            const int gy = q.y0 - 1 + py, gx = q.x0 - 1 + px;
+            const bool ok = v < G::NV && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const unsigned off = ok ? (unsigned)(part >> 2) * plane_bytes + (unsigned)(gy * W + gx) * 64u + (unsigned)(part & 3) * 16u : 0u;
+            okm |= ok ? (1u << it) : 0u;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(regs_n[it]) : "v"(off), "s"(inb) : "memory");
+        }
+    };
+    auto store_tile = [&](int tid) {
+#pragma unroll
+        for (int it = 0; it < G::ITER; ++it) {
+            const int v = tid + it * 256;
+            if (v < G::NV) {
+                int p, part;
+                vec_map<G>(v, 1, p, part);
+                const int u = part & 3;
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4*>(smem_a + (u & 1) * G::TILE_BYTES + p * G::PS + 32 * (part >> 2) + 16 * (u >> 1)) =
+                    ((okm >> it) & 1u) ? regs_n[it] : z;
+            }
+        }
+    };
+    auto wait_regs = [&]() {   // every vector-memory operation is done; the registers are valid from here
+        static_assert(G::ITER == 11, "register list below");
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(regs_n[0]), "+v"(regs_n[1]), "+v"(regs_n[2]), "+v"(regs_n[3]), "+v"(regs_n[4]), "+v"(regs_n[5]),
+                       "+v"(regs_n[6]), "+v"(regs_n[7]), "+v"(regs_n[8]), "+v"(regs_n[9]), "+v"(regs_n[10])
+                     :
+                     : "memory");
+    };
+
+    TileXY cur = decode(t);
+    int par = 0;
+    {
+        const int tid0 = threadIdx.x;
+        const int wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+        prefetch(cur, tid0);
+        const u32x4* wsrc0 = reinterpret_cast<const u32x4*>(a.wpack) + (size_t)blockIdx.y * a.wstride_cb + tid0;
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc0 + it * 256),
+                                             (__attribute__((address_space(3))) void*)(smem + wave0 * 1024 + it * 4096), 16, 0, 0);
+        wait_regs();
+        store_tile(tid0);
+        bar();
+    }
+
+    for (;;) {
+        const int tn = t + (int)gridDim.x;
+        const bool have_next = tn < ntiles;
+        const TileXY nxt = decode(have_next ? tn : t);
+        // the thread index passes through an opaque copy per tile: otherwise every lane-constant address of the body is hoisted
+        // out of the tile loop and the kernel spills
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int r = lane & 31, h = lane >> 5;
+        const int b = cur.b, y0 = cur.y0, x0 = cur.x0;
+        const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpack) + (size_t)blockIdx.y * a.wstride_cb + tid;
+        auto tapbuf = [&](int i) { return smem + (i ? TAPB + A_BYTES : 0); };
+        auto dma_tap = [&](int q, int buf) {
+            unsigned char* dst = tapbuf(buf) + wave * 1024;
+#pragma unroll
+            for (int it = 0; it < WIT; ++it)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)q * TAPV + it * 256),
+                                                 (__attribute__((address_space(3))) void*)(dst + it * 4096), 16, 0, 0);
+        };
+        f32x16 acc[G::MT][2];
+        f32x16 pk[4];
+        auto tap_iter = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int pass = q < 4 ? 0 : (q < 6 ? 1 : (q < 8 ? 2 : 3));
+            constexpr int tidx = q < 4 ? q : (q < 6 ? q - 4 : (q < 8 ? q - 6 : 0));
+            constexpr int tap = pass_tap(M_CONVT, pass, tidx);
+            constexpr bool first = tidx == 0, last = tidx + 1 == pass_ntaps(M_CONVT, pass);
+            if (q + 1 < 9) dma_tap(q + 1, (q + 1 + par) & 1);      // that buffer (tap q-1) was released by the last barrier
+            else if (have_next) dma_tap(0, par ^ 1);               // tap 8: the next tile's tap 0 into the buffer tap 7 was in
+            if (q == 7 && have_next) prefetch(nxt, tid);           // younger than tap 8's DMA
+            if (first) zero_acc<G, 2>(acc);
+            const unsigned char* bq = tapbuf((q + par) & 1) + lane * 16;
+            u32x4 fa[2][G::MT][G::AV], fb[2][NB];
+            load_a<G, M_CONVT>(fa[0], smem_a, tap, 0, wave, r, h);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) fb[0][j] = *reinterpret_cast<const u32x4*>(bq + j * 1024);
+#pragma unroll
+            for (int i = 0; i < STEPS; ++i) {
+                if (i + 1 < STEPS) {
+                    load_a<G, M_CONVT>(fa[(i + 1) & 1], smem_a, tap, i + 1, wave, r, h);
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        fb[(i + 1) & 1][j] = *reinterpret_cast<const u32x4*>(bq + ((i + 1) * NB + j) * 1024);
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    mma_wx<PREC, true>(acc[0][n], fb[i & 1][n * 2 + 0], fa[i & 1][0][1]);   // w_hi * x_lo
+                    mma_wx<PREC, true>(acc[0][n], fb[i & 1][n * 2 + 1], fa[i & 1][0][0]);   // w_lo * x_hi
+                    mma_wx<PREC, true>(acc[0][n], fb[i & 1][n * 2 + 0], fa[i & 1][0][0]);   // w_hi * x_hi
+                }
+            }
+            if (last) proj_compute<G, PREC>(acc, a, pr, pk[pass]);
+            if (q + 1 < 9) {
+                // this wave's part of tap q+1 has landed (at tap 7 the eleven younger loads of the next tile stay in flight)
+                if (q == 7 && have_next) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bar();
+            }
+        };
+        static_assert(G::ITER == 11, "the counted wait of tap 7");
+        tap_iter(std::integral_constant<int, 0>{});
+        tap_iter(std::integral_constant<int, 1>{});
+        tap_iter(std::integral_constant<int, 2>{});
+        tap_iter(std::integral_constant<int, 3>{});
+        tap_iter(std::integral_constant<int, 4>{});
+        tap_iter(std::integral_constant<int, 5>{});
+        tap_iter(std::integral_constant<int, 6>{});
+        tap_iter(std::integral_constant<int, 7>{});
+        tap_iter(std::integral_constant<int, 8>{});
+
+        // the next tile's input and first tap have landed (nothing younger is in flight yet: the gather's stores come below)
+        if (have_next) wait_regs();
+        bar();        // every wave is done with the input tile and with tap 8's buffer
+        float* const PT = reinterpret_cast<float*>(smem + (par ? TAPB : 0));
+        {
+            const bool in_img = y0 + wave < H && x0 + r < W;   // records outside the image contribute nothing
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                float* rec = PT + (((2 * wave + (pass >> 1)) * 64 + 2 * r + (pass & 1)) * PTS + 4 * h);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (8 * g + j < 23 || (8 * g + j < 27 && h == 0)) rec[8 * g + j] = in_img ? pk[pass][4 * g + j] : 0.f;
+            }
+        }
+        bar();
+        {
+            const int Ho = 2 * H, Wo = 2 * W, oy0 = 2 * y0, ox0 = 2 * x0;
+            const size_t simg = (size_t)a.B * Ho * Wo * 4;
+            float* const S = reinterpret_cast<float*>(a.out);
+            const float hi = a.gather_act == A_CLIP01 ? 1.f : INFINITY;
+            const float lo = a.gather_act == A_NONE ? -INFINITY : 0.f;
+            auto finish = [&](int ly, int lx) {
+                const bool rin = (unsigned)ly < 8u, cin = (unsigned)lx < 64u;
+                const bool inner = ly > 0 && ly < 7 && lx > 0 && lx < 63;
+                float o[3];
+#pragma unroll
+                for (int co = 0; co < 3; ++co) o[co] = inner ? a.gather_bias[co] : 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int sy = ly + ky - 1, sx = lx + kx - 1;
+                        const bool ok = (unsigned)sy < 8u && (unsigned)sx < 64u;
+                        const float* pp = PT + (ok ? (sy * 64 + sx) * PTS : 0) + (ky * 3 + kx) * 3;
+#pragma unroll
+                        for (int co = 0; co < 3; ++co) {
+                            const float v = pp[co];
+                            o[co] += ok ? v : 0.f;
+                        }
+                    }
+                const int gy = oy0 + ly, gx = ox0 + lx;
+                if (gy < 0 || gx < 0 || gy >= Ho || gx >= Wo) return;
+                const size_t pix = ((size_t)b * Ho + gy) * Wo + gx;
+                if (inner) {
+                    float* op = a.gather_out + pix * a.gather_cs;
+#pragma unroll
+                    for (int co = 0; co < 3; ++co)
+                        if (co < a.gather_cout) op[co] = fminf(fmaxf(o[co], lo), hi);
+                } else {
+                    const int k = (rin ? 0 : 2) + (cin ? 0 : 1);
+                    *reinterpret_cast<f32x4*>(S + k * simg + pix * 4) = f32x4{o[0], o[1], o[2], 0.f};
+                }
+            };
+            finish(tid >> 5, tid & 31);
+            finish(tid >> 5, 32 + (tid & 31));
+            if (tid < 66) finish(-1, tid - 1);
+            else if (tid < 132) finish(8, tid - 67);
+            else if (tid < 140) finish(tid - 132, -1);
+            else if (tid < 148) finish(tid - 140, 64);
+        }
+        if (!have_next) break;
+        bar();        // the records have been read: the input tile region takes the next tile
+        store_tile(tid);
+        bar();
+        t = tn;
+        cur = nxt;
+        par ^= 1;
+    }
+}
+
 size_t conv_lds_bytes(int prec, int mode, int nt, int steps, int mt) {
     const int th = mode == M_CONV ? 4 * mt : 4, hb = mode == M_CONV ? 1 : 0;
     const size_t tile = (size_t)(th + 1 + hb) * (TW + 1 + hb) * (32 * steps + 16);
@@ -1424,6 +1681,30 @@ static hipError_t launch_one(const ConvArgs& a, int ncb, hipStream_t s) {
                         (a.gather_act != A_NONE && a.gather_act != A_RELU && a.gather_act != A_CLIP01))
                         return hipErrorInvalidValue;
                     lds = std::max(lds, (size_t)GATHER_LDS);
+                }
+                if constexpr (PREC == P_BF16X3 && STEPS == 4) {
+                    static const bool no_persist = getenv("SR_NO_PERSIST_UP2") != nullptr;   // A/B switch
+                    if (a.gather_out && a.in_split && a.in_planar && !no_persist && !(a.dbg & (256 | 512 | 1024 | 2048)) &&
+                        (double)a.H * a.W * 256.0 < 4.0e9) {
+                        static bool attr3 = false;
+                        const size_t lds3 = conv_lds_bytes(PREC, MODE, NT, STEPS, 1);
+                        if (!attr3) {
+                            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convT3x3_gather_kernel<PREC, STEPS>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                            if (e != hipSuccess) return e;
+                            attr3 = true;
+                        }
+                        ConvArgs b = a;
+                        b.tiles_x = (a.W + TW - 1) / TW;
+                        b.tiles_y = (a.H + 3) / 4;
+                        const int nt_all = b.tiles_x * b.tiles_y * b.B;
+                        if (nt_all <= 0) return hipSuccess;
+                        const int slots = 2 * num_cus();
+                        const int rounds = (nt_all + slots - 1) / slots;
+                        const int gx = (nt_all + rounds - 1) / rounds;       // every workgroup the same number of tiles (+-1)
+                        hipLaunchKernelGGL((convT3x3_gather_kernel<PREC, STEPS>), dim3(gx, 1), dim3(256), lds3, s, b);
+                        return hipGetLastError();
+                    }
                 }
                 return launch_k(&convT3x3_lds_kernel<PREC, STEPS>, lds, a, 4, ncb, s, attr2, 0);
             }
