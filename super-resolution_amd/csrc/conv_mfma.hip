@@ -1683,7 +1683,7 @@ static hipError_t launch_one(const ConvArgs& a, int ncb, hipStream_t s) {
                     lds = std::max(lds, (size_t)GATHER_LDS);
                 }
                 if constexpr (PREC == P_BF16X3 && STEPS == 4) {
-                    static const bool no_persist = getenv("SR_NO_PERSIST_UP2") != nullptr;   // A/B switch
+                    const bool no_persist = getenv("SR_NO_PERSIST_UP2") != nullptr;   // A/B switch, read per launch (two launches per step)
                     if (a.gather_out && a.in_split && a.in_planar && !no_persist && !(a.dbg & (256 | 512 | 1024 | 2048)) &&
                         (double)a.H * a.W * 256.0 < 4.0e9) {
                         static bool attr3 = false;

@@ -160,6 +160,30 @@ def test_in_kernel_tap_gather_is_the_gather_kernel(sh, weights7, B, h, w, dtype)
     assert np.abs(fused - separate).max() <= 2e-6
 
 
+@pytest.mark.parametrize("B,h,w", [(2, 24, 40), (1, 8, 72), (3, 16, 8), (1, 96, 144), (5, 8, 8), (1, 40, 136)])
+def test_persistent_x4_tail_is_the_one_tile_kernel(sh, weights7, B, h, w):
+    """convT3x3_gather_kernel (a workgroup walks many tiles, next tile prefetched under the current one) against the same
+    arithmetic with one tile per workgroup (SR_NO_PERSIST_UP2=1): every sum in the same order, bit for bit.  Shapes: fewer
+    tiles than workgroup slots and more (96 x 144: 1728 tiles on 512 slots, several tiles per workgroup with both tap-buffer
+    parities), ragged right edges, several images."""
+    lr_t, lr_tm1, est = step_inputs(350 + h, B, h, w)
+    outs = []
+    os.environ["SR_SPLIT_TRUNK"] = "2"       # the split-planar trunk (whose tail this is) at any size
+    try:
+        for off in (False, True):
+            if off:
+                os.environ["SR_NO_PERSIST_UP2"] = "1"
+            ctx = make_ctx(sh, weights7, h, w, B, dtype="bf16x3")
+            outs.append(ctx.step(lr_t, lr_tm1, est)[0])
+            ctx.close()
+    finally:
+        os.environ.pop("SR_NO_PERSIST_UP2", None)
+        os.environ.pop("SR_SPLIT_TRUNK", None)
+    assert np.array_equal(outs[0], outs[1])
+    want, _ = rt.generator_step(weights7, lr_t, lr_tm1, est)
+    assert np.abs(outs[0] - want).max() <= FP32_TOL
+
+
 def test_golden_clip24x40(sh, weights7):
     g = np.load(os.path.join(GOLD, "clip24x40.npz"))
     clip = rn.synth_clip(int(g["clip_id"]), 3, 24, 40)[:, None]
