@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16x3")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--e2e", action="store_true", help="also bench.py's end_to_end leg (host float32 frames in, uint8 frames out)")
     args = ap.parse_args()
     import torch
     import sr_hip
@@ -39,6 +40,9 @@ def main():
         out["kernel_ms_per_step"] = {p["name"]: round(p["ms_total"] / n, 4) for p in prof}
         out["kernel_ms_per_step"]["_sum"] = round(sum(p["ms_total"] for p in prof) / n, 4)
     ctx.close()
+    if args.e2e:
+        out["end_to_end"] = bench.end_to_end(torch, sr_hip, weights, lr, args.dtype, 0, 50)
+        out["end_to_end"].pop("what")
     print(json.dumps(out), flush=True)
 
 
