@@ -408,7 +408,8 @@ __global__ __launch_bounds__(256, 2) void tap_gather_kernel(const ConvArgs a) {
 // tile, one thread per pixel of its outermost ring.  out = act(bias + S0 + S1 + S2 + S3): the tile's own part, then the parts of the
 // horizontal, vertical and diagonal neighbour, where the pixel has them -- a fixed order, so results do not depend on scheduling.
 __global__ __launch_bounds__(192) void gather_fix_kernel(const float* __restrict__ S, float* __restrict__ out, const float* __restrict__ bias,
-                                                         int B, int Ho, int Wo, int tiles_x, int tiles_y, int out_cs, int cout, int act) {
+                                                         int B, int Ho, int Wo, int tiles_x, int tiles_y, int out_cs, int cout, int act,
+                                                         int th) {
     int t = blockIdx.x;
     const int tx = t % tiles_x;
     t /= tiles_x;
@@ -416,15 +417,16 @@ __global__ __launch_bounds__(192) void gather_fix_kernel(const float* __restrict
     const int b = t / tiles_y;
     const int slot = threadIdx.x;
     int ly, lx;
+    // th = rows of the output tile (8: convT3x3_lds_kernel / convT3x3_gather_kernel, 16: tail_kernel)
     if (slot < 64) ly = 0, lx = slot;
-    else if (slot < 128) ly = 7, lx = slot - 64;
-    else if (slot < 134) ly = slot - 127, lx = 0;
-    else if (slot < 140) ly = slot - 133, lx = 63;
+    else if (slot < 128) ly = th - 1, lx = slot - 64;
+    else if (slot < 126 + th) ly = slot - 127, lx = 0;
+    else if (slot < 124 + 2 * th) ly = slot - (125 + th), lx = 63;
     else return;
-    const int gy = 8 * ty + ly, gx = 64 * tx + lx;
+    const int gy = th * ty + ly, gx = 64 * tx + lx;
     if (gy >= Ho || gx >= Wo) return;
     const bool hz = (lx == 0 && gx > 0) || (lx == 63 && gx + 1 < Wo);
-    const bool vt = (ly == 0 && gy > 0) || (ly == 7 && gy + 1 < Ho);
+    const bool vt = (ly == 0 && gy > 0) || (ly == th - 1 && gy + 1 < Ho);
     const size_t simg = (size_t)B * Ho * Wo * 4;
     const size_t pix = ((size_t)b * Ho + gy) * Wo + gx;
     const f32x4 s0 = *reinterpret_cast<const f32x4*>(S + pix * 4);
@@ -495,14 +497,14 @@ hipError_t launch_tap_gather(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_gather_fix(const ConvArgs& a, hipStream_t s) {
-    if (!a.gather_out || !a.gather_bias || a.gather_cout > 3) return hipErrorInvalidValue;
-    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + 3) / 4;   // the transposed conv's tiles: 4 x 32 input pixels
+hipError_t launch_gather_fix(const ConvArgs& a, hipStream_t s, int th_in) {
+    if (!a.gather_out || !a.gather_bias || a.gather_cout > 3 || (th_in != 4 && th_in != 8)) return hipErrorInvalidValue;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + th_in - 1) / th_in;   // the transposed conv's tiles: th_in x 32 input pixels
     const long n = (long)tiles_x * tiles_y * a.B;
     if (n <= 0) return hipSuccess;
     if (n > 0x7fffffffL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gather_fix_kernel, dim3((unsigned)n), dim3(192), 0, s, reinterpret_cast<const float*>(a.out), a.gather_out,
-                       a.gather_bias, a.B, 2 * a.H, 2 * a.W, tiles_x, tiles_y, a.gather_cs, a.gather_cout, a.gather_act);
+                       a.gather_bias, a.B, 2 * a.H, 2 * a.W, tiles_x, tiles_y, a.gather_cs, a.gather_cout, a.gather_act, 2 * th_in);
     return hipGetLastError();
 }
 

@@ -90,6 +90,25 @@ struct TrunkArgs {
 hipError_t launch_trunk_conv(TrunkArgs a, hipStream_t s);
 hipError_t launch_trunk_convT(TrunkArgs a, hipStream_t s);   // conv2d_transpose_1, split-planar in and out
 size_t trunk_weight_bytes();
+// SRNet's x4 tail on a split-planar input (conv_tail.hip): conv2d_transpose_2 + ReLU + conv2d_36's tap projection and nine-tap
+// sum; interior pixels of the 16 x 64 output tiles go to `img`, the tiles' border rings as partial sums to `S` (launch_gather_fix
+// with th = 16 finishes them)
+struct TailArgs {
+    const unsigned char* in;       // [B][4 planes][H][W][64 B], H x W = the transposed conv's INPUT size
+    const unsigned char* wpack;    // trunkT_entries packing of conv2d_transpose_2
+    const float* bias;             // [64]
+    const unsigned char* proj_w;   // ConvLayer::d_proj (bf16x3: 8 KiB)
+    const float* gbias;            // [<= 3] conv2d_36's bias
+    float* img;                    // [B][2H][2W][gather_cs]
+    float* S;                      // [4][B][2H][2W][4] partial sums
+    unsigned zero_off;             // byte offset from `in` of 64 zero bytes
+    int B, H, W;
+    int act;                       // A_RELU (or A_NONE) between the two convs
+    int gather_cs, gather_cout, gather_act;
+    int tiles_x, tiles_y;          // set by the launcher
+    int dbg;                       // ablations of the micro-benchmark (SR_TAIL_DBG; 0 in production): 1 no tap sum, 2 no projection, 4 no DMA
+};
+hipError_t launch_tail(TailArgs a, hipStream_t s);
 // channel of k index (half h, element e) inside a 16-channel plane of the split-planar layout
 __host__ __device__ constexpr int split_perm(int h, int e) { return e < 4 ? 4 * h + e : 8 + 4 * h + (e - 4); }
 
@@ -99,7 +118,7 @@ hipError_t launch_conv_tapsn(int prec, int nchunk, const ConvArgs& a, hipStream_
 // out[y,x,co] = act(bias[co] + sum_tap P[y+ky-1, x+kx-1][tap*3+co]) (+ residual); a.in = P [B,H,W,32] fp32
 hipError_t launch_tap_gather(const ConvArgs& a, hipStream_t s);
 // finishes the tile-border pixels of an in-kernel gather (ConvArgs::gather_out): a = the transposed conv's arguments
-hipError_t launch_gather_fix(const ConvArgs& a, hipStream_t s);
+hipError_t launch_gather_fix(const ConvArgs& a, hipStream_t s, int th_in = 4);   // th_in: input rows per tile (output tile 2 th_in x 64)
 constexpr int GATHER_LDS = 8 * 64 * 33 * 4;   // the P records of one 8 x 64 output tile, 33-float rows
 size_t conv_lds_bytes(int prec, int mode, int nt, int steps, int mt);
 

@@ -224,7 +224,7 @@ int upload_alt(sr_ctx* c, ConvLayer& L, size_t bytes, const float* w) {
 }
 
 void free_layer(ConvLayer& L) {
-    void* ps[] = {L.d_w, L.d_bias, L.d_proj, L.d_ents, L.d_proj_ents, L.d_w2, L.d_ents2};
+    void* ps[] = {L.d_w, L.d_bias, L.d_proj, L.d_ents, L.d_proj_ents, L.d_w2, L.d_ents2, L.d_w3, L.d_ents3};
     for (void* p : ps)
         if (p) (void)hipFree(p);
     L.d_w = nullptr;
@@ -234,6 +234,8 @@ void free_layer(ConvLayer& L) {
     L.d_proj_ents = nullptr;
     L.d_w2 = nullptr;
     L.d_ents2 = nullptr;
+    L.d_w3 = nullptr;
+    L.d_ents3 = nullptr;
 }
 
 // Tap-projection weights for conv_mfma.hip epilogue_proj: the following conv's kernel w[3,3,64,cout<=3]
@@ -584,6 +586,29 @@ int run_srnet(sr_ctx* c, int B, float* d_out, bool split) {
         // conv2d_transpose_2 + ReLU + the 64 x 27 tap projection of conv2d_36 in one kernel ...
         ConvIO up2 = {b("up1"), 2 * H, 2 * W, b("up2"), 32, 32, 1, nullptr, 0, A_RELU, u2p, 0, c->srnet[22].d_proj};
         up2.in_split = u2p;
+        if (c->fuse_gather && u2p && c->srnet[22].d_w3 && !g_conv_dbg) {
+            // conv_tail.hip: the same three layers plane-major on a trunk-style kernel, then the border fix-up on its 16 x 64 tiles
+            const ConvLayer& L = c->srnet[22];
+            const size_t left = (size_t)(c->max_batch - c->lane_b0);
+            const size_t tail_in = left * H * W * 1024;      // behind the lane's part of "up1": [left][4 planes][2H][2W][64 B]
+            if (tail_in + 4096 > 4294967295.0) return fail(c, SR_ERR_ARG, "srnet.up2: tensor too large for 32-bit offsets");
+            TailArgs ta = {(const unsigned char*)b("up1"), (const unsigned char*)L.d_w3, L.d_bias, (const unsigned char*)L.d_proj,
+                           c->srnet[23].d_bias, d_out, (float*)b("up2"), (unsigned)tail_in, B, 2 * H, 2 * W, A_RELU, 3, 3, A_CLIP01, 0, 0};
+            ConvArgs fx = {};
+            fx.out = b("up2");
+            fx.gather_out = d_out;
+            fx.gather_bias = c->srnet[23].d_bias;
+            fx.gather_cs = fx.gather_cout = 3;
+            fx.gather_act = A_CLIP01;
+            fx.B = B;
+            fx.H = 2 * H;
+            fx.W = 2 * W;
+            const double px = (double)B * 4 * H * W;
+            ProfScope ps(c, "srnet.up2", px * 9.0 * 64 * 64 * 2.0, px * 256.0 + 4 * px * (12.0 + 2.0 * 16.0 * (156 + 164) / 1024.0) + 2.0 * trunk_weight_bytes());
+            LAUNCHCHK(c, "srnet.up2", launch_tail(ta, st));
+            LAUNCHCHK(c, "srnet.up2.fix", launch_gather_fix(fx, st, 8));
+            return SR_OK;
+        }
         if (c->fuse_gather) {
             // ... and conv2d_36's nine-tap sum + clip as well: the kernel writes the image, except the tile-border pixels, whose
             // partial sums ("up2": 4 x 16 B per HR pixel, sparsely written) a small second kernel adds (ConvArgs::gather_out)
@@ -776,6 +801,7 @@ static int create_common(sr_ctx** out, int device, int h_in, int w_in, int ch, i
     c->fuse_pool = getenv("SR_NO_FUSE_POOL") ? 0 : 1;
     c->fuse_gather = getenv("SR_NO_FUSE_GATHER") ? 0 : 1;
     c->trunk_up1 = getenv("SR_NO_TRUNK_UP1") ? 0 : 1;
+    if (const char* e = getenv("SR_TAIL")) c->tail_kernel = atoi(e);
     if (const char* e = getenv("SR_SPLIT_TRUNK")) c->split_trunk = atoi(e);
     int rc = SR_OK;
     auto bail = [&](int code) {
@@ -952,6 +978,15 @@ int sr_commit_weights(sr_ctx* c) {
             int rc = upload_alt(c, L, bytes, c->tensors[28 + 2 * i].data.data());
             if (rc) return rc;
         }
+    }
+    if (c->prec == P_BF16X3 && c->split_trunk && c->trunk_up1 && c->tail_kernel) {   // conv_tail.hip reads conv2d_transpose_2 in trunkT order
+        ConvLayer& L = c->srnet[22];
+        L.ents3 = trunkT_entries(L.cin, L.cout);
+        std::vector<uint8_t> packed = pack_apply(L.ents3, trunk_weight_bytes(), P_BF16X3, c->tensors[28 + 2 * 22].data.data());
+        if (L.d_w3) (void)hipFree(L.d_w3);
+        L.d_w3 = nullptr;
+        HIPCHK(c, hipMalloc(&L.d_w3, packed.size()));
+        HIPCHK(c, hipMemcpy(L.d_w3, packed.data(), packed.size(), hipMemcpyHostToDevice));
     }
     if (!getenv("SR_NO_FUSE_OUT")) {   // SRNet tail: conv2d_transpose_2 carries conv2d_36's tap projection
         int rc = upload_proj(c, c->srnet[22], c->prec, c->tensors[28 + 2 * 23].data.data(), 3);

@@ -45,6 +45,10 @@ struct ConvLayer {
     void* d_w2 = nullptr;
     std::vector<PackEnt> ents2;
     PackEnt* d_ents2 = nullptr;
+    // third packing, conv2d_transpose_2 only: conv_trunk.hip's transposed-conv order for conv_tail.hip's tail_kernel
+    void* d_w3 = nullptr;
+    std::vector<PackEnt> ents3;
+    PackEnt* d_ents3 = nullptr;
     double wbytes = 0;
     // packing lists (kept for the device re-pack)
     std::vector<PackEnt> ents, proj_ents;
@@ -97,6 +101,7 @@ struct sr_ctx {
     // 2 = always (SR_SPLIT_TRUNK=2, tests), 0 = never (SR_SPLIT_TRUNK=0)
     int split_trunk = 1;
     int trunk_up1 = 1;                   // split-planar path: conv2d_transpose_1 on conv_trunk.hip (SR_NO_TRUNK_UP1=1: generic kernel)
+    int tail_kernel = 0;                 // ... as conv_tail.hip's plane-major tail_kernel (SR_TAIL=1; needs trunk_up1 and fuse_gather)
     int fuse_gather = 1;                 // SRNet tail: conv2d_36's tap sum inside conv2d_transpose_2's kernel (SR_NO_FUSE_GATHER=1: tap_gather_kernel)
     int fuse_pool = 1;                   // FNet: MaxPooling2D in the producing conv's epilogue (SR_NO_FUSE_POOL=1: separate kernel)
     bool step_split = false;   // the step being enqueued uses it

@@ -107,6 +107,7 @@ int train_init(sr_ctx* c) {
             if ((rc = upload_ents(c, L.ents, &L.d_ents))) return rc;
             if ((rc = upload_ents(c, L.proj_ents, &L.d_proj_ents))) return rc;
             if (L.d_w2 && (rc = upload_ents(c, L.ents2, &L.d_ents2))) return rc;
+            if (L.d_w3 && (rc = upload_ents(c, L.ents3, &L.d_ents3))) return rc;
             // spatial size of the layer's input, for the wgrad workspace
             int H = h, W = w;
             if (is_f) {
@@ -531,6 +532,7 @@ int repack_all(sr_ctx* c) {
             const size_t wk = T->off[base + 2 * i];
             RC(add(L.d_ents, (int)L.ents.size(), L.d_w, wk));
             if (L.d_w2) RC(add(L.d_ents2, (int)L.ents2.size(), L.d_w2, wk));   // split-planar trunk packing
+            if (L.d_w3) RC(add(L.d_ents3, (int)L.ents3.size(), L.d_w3, wk));   // conv_tail.hip's packing of conv2d_transpose_2
             RC(add(nullptr, L.cout, L.d_bias, T->off[base + 2 * i + 1]));
             ConvLayer& D = is_f ? T->fnet_dg[i] : T->srnet_dg[i];
             if (D.d_w) RC(add(D.d_ents, (int)D.ents.size(), D.d_w, wk));

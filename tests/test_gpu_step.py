@@ -184,6 +184,32 @@ def test_persistent_x4_tail_is_the_one_tile_kernel(sh, weights7, B, h, w):
     assert np.abs(outs[0] - want).max() <= FP32_TOL
 
 
+@pytest.mark.parametrize("B,h,w", [(2, 24, 40), (1, 8, 72), (3, 16, 8), (1, 96, 144), (5, 8, 8), (1, 40, 136), (2, 8, 16)])
+def test_plane_major_x4_tail(sh, weights7, B, h, w):
+    """conv_tail.hip's tail_kernel (SR_TAIL=1: conv2d_transpose_2 + conv2d_36 plane-major on 16 x 64 output tiles, two-pass tap
+    sum) against the tap-major kernel and the oracle.  The same products summed in another order: a few ulp between the kernels,
+    the fp32 bar against the oracle.  Shapes: ragged right / bottom edges (4w = 32, 160, 288, 544, 576 columns on 64-column tiles,
+    2h = 16, 32, 48, 80 rows on 8-row input tiles), several images, more tiles than workgroups."""
+    lr_t, lr_tm1, est = step_inputs(370 + h, B, h, w)
+    outs = []
+    os.environ["SR_SPLIT_TRUNK"] = "2"
+    try:
+        for tail in (False, True):
+            if tail:
+                os.environ["SR_TAIL"] = "1"
+            else:
+                os.environ["SR_TAIL"] = "0"
+            ctx = make_ctx(sh, weights7, h, w, B, dtype="bf16x3")
+            outs.append(ctx.step(lr_t, lr_tm1, est)[0])
+            ctx.close()
+    finally:
+        os.environ.pop("SR_TAIL", None)
+        os.environ.pop("SR_SPLIT_TRUNK", None)
+    want, _ = rt.generator_step(weights7, lr_t, lr_tm1, est)
+    assert np.abs(outs[1] - want).max() <= FP32_TOL
+    assert np.abs(outs[1] - outs[0]).max() <= 5e-6
+
+
 def test_golden_clip24x40(sh, weights7):
     g = np.load(os.path.join(GOLD, "clip24x40.npz"))
     clip = rn.synth_clip(int(g["clip_id"]), 3, 24, 40)[:, None]
