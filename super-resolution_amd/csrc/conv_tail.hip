@@ -56,7 +56,8 @@ struct TL {
     static constexpr int PTS = 29;                           // floats per gather record (27 used; odd: conflict-free column reads)
     static constexpr int REC_ROWS = 9;
     static constexpr int OFF_BIAS = OFF_F + PROJ_BYTES;      // 64 floats
-    static constexpr int OFF_REC = OFF_BIAS + 256;
+    static constexpr int OFF_ZREC = OFF_BIAS + 256;          // one record of zeros: what a tap outside the tile reads
+    static constexpr int OFF_REC = OFF_ZREC + 128;
     static constexpr int REC_BYTES = REC_ROWS * 64 * PTS * 4;
     static_assert(OFF_REC + REC_BYTES <= LDS, "records fit behind the projection weights");
     static_assert(OFF_F + PROJ_BYTES <= OFF_A1, "projection weights stay clear of the plane buffers");
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(const TailArgs a) {
     // conv2d_36's in registers
     float* const lbias = reinterpret_cast<float*>(smem + TL::OFF_BIAS);
     if (tid < 64) lbias[tid] = a.bias[tid];
+    else if (tid < 96) reinterpret_cast<float*>(smem + TL::OFF_ZREC)[tid - 64] = 0.f;
     float gb[3];
 #pragma unroll
     for (int co = 0; co < 3; ++co) gb[co] = co < a.gather_cout ? a.gbias[co] : 0.f;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(const TailArgs a) {
     };
     float* const PT = reinterpret_cast<float*>(smem + TL::OFF_REC);
     const unsigned char* const pwl = smem + TL::OFF_F + lane * 16;
-    const float slope = a.act == A_RELU ? 0.f : 1.f;
+    const bool relu = a.act == A_RELU;
 
     for (;;) {
         const int tn = t + nslots;
@@ -254,8 +256,10 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(const TailArgs a) {
                     for (int e = 0; e < 4; ++e) {
                         const int i0 = 8 * s + 2 * e;      // k index 2e, 2e + 1 of step (n, s) = accumulator registers 8s + 2e, + 1
                         float v0 = acc[pq][n][i0], v1 = acc[pq][n][i0 + 1];
-                        v0 = fmaxf(v0, slope * v0);
-                        v1 = fmaxf(v1, slope * v1);
+                        if (relu) {
+                            v0 = fmaxf(v0, 0.f);
+                            v1 = fmaxf(v1, 0.f);
+                        }
                         const unsigned hi = pack_bf16_2(v0, v1);
                         xh4[e] = hi;
                         xl4[e] = pack_bf16_2(v0 - __builtin_bit_cast(float, hi << 16), v1 - __builtin_bit_cast(float, hi & 0xFFFF0000u));
@@ -325,12 +329,10 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(const TailArgs a) {
                 for (int kx = 0; kx < 3; ++kx) {
                     const int sy = ly + ky - 1, sx = lx + kx - 1;
                     const bool ok = (unsigned)sy < 16u && (unsigned)sx < 64u;
-                    const float* pp = PT + (ok ? ((sy - base) * 64 + sx) * TL::PTS : 0) + (ky * 3 + kx) * 3;
+                    // a tap outside the tile reads the zero record (32 floats in front of the records)
+                    const float* pp = PT + (ok ? ((sy - base) * 64 + sx) * TL::PTS + (ky * 3 + kx) * 3 : -32);
 #pragma unroll
-                    for (int co = 0; co < 3; ++co) {
-                        const float v = pp[co];
-                        o[co] += ok ? v : 0.f;
-                    }
+                    for (int co = 0; co < 3; ++co) o[co] += pp[co];
                 }
             const int gy = oy0 + ly, gx = ox0 + lx;
             if (gy < 0 || gx < 0 || gy >= Ho || gx >= Wo) return;
@@ -367,23 +369,26 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(const TailArgs a) {
             continue;
         }
         bar();      // every wave is done with plane 3's buffers (A1, W1): the records may overwrite them
-        if (wave < 4) {
+        if (DBG & 16) {
+        } else if (wave < 4) {
             put_row(0, 2 * wave);
             put_row(1, 2 * wave + 1);
         } else if (wave == 4) {
             put_row(0, 8);
         }
         bar();
-        pass(0);
+        if (!(DBG & 8)) pass(0);
         bar();
-        if (wave == 3) {
+        if (DBG & 16) {
+            asm volatile("" ::"v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3]));
+        } else if (wave == 3) {
             put_row(1, 0);                                    // row 7
         } else if (wave >= 4) {
             put_row(0, 2 * wave - 7);
             put_row(1, 2 * wave - 6);
         }
         bar();
-        pass(1);
+        if (!(DBG & 8)) pass(1);
         if (!have_next) break;
         t = tn;
         cur = nxt;
@@ -430,6 +435,9 @@ hipError_t launch_tail(TailArgs a, hipStream_t s) {
     const int rounds = (per_xcd + nslots - 1) / nslots;
     nslots = (per_xcd + rounds - 1) / rounds;      // every workgroup the same number of tiles (+-1)
     static const int dbg = getenv("SR_TAIL_DBG") ? atoi(getenv("SR_TAIL_DBG")) : 0;
+    if (dbg == 8) return launch_tail_t<8>(a, 8 * nslots, s);
+    if (dbg == 16) return launch_tail_t<16>(a, 8 * nslots, s);
+    if (dbg == 24) return launch_tail_t<24>(a, 8 * nslots, s);
     switch (dbg & 7) {
         case 0: return launch_tail_t<0>(a, 8 * nslots, s);
         case 1: return launch_tail_t<1>(a, 8 * nslots, s);

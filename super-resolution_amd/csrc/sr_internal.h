@@ -101,7 +101,7 @@ struct sr_ctx {
     // 2 = always (SR_SPLIT_TRUNK=2, tests), 0 = never (SR_SPLIT_TRUNK=0)
     int split_trunk = 1;
     int trunk_up1 = 1;                   // split-planar path: conv2d_transpose_1 on conv_trunk.hip (SR_NO_TRUNK_UP1=1: generic kernel)
-    int tail_kernel = 0;                 // ... as conv_tail.hip's plane-major tail_kernel (SR_TAIL=1; needs trunk_up1 and fuse_gather)
+    int tail_kernel = 1;                 // ... as conv_tail.hip's plane-major tail_kernel (SR_TAIL=0: convT3x3_gather_kernel; needs trunk_up1 and fuse_gather)
     int fuse_gather = 1;                 // SRNet tail: conv2d_36's tap sum inside conv2d_transpose_2's kernel (SR_NO_FUSE_GATHER=1: tap_gather_kernel)
     int fuse_pool = 1;                   // FNet: MaxPooling2D in the producing conv's epilogue (SR_NO_FUSE_POOL=1: separate kernel)
     bool step_split = false;   // the step being enqueued uses it

@@ -169,6 +169,7 @@ def test_persistent_x4_tail_is_the_one_tile_kernel(sh, weights7, B, h, w):
     lr_t, lr_tm1, est = step_inputs(350 + h, B, h, w)
     outs = []
     os.environ["SR_SPLIT_TRUNK"] = "2"       # the split-planar trunk (whose tail this is) at any size
+    os.environ["SR_TAIL"] = "0"              # the tap-major kernels (conv_tail.hip's plane-major kernel is the default)
     try:
         for off in (False, True):
             if off:
@@ -179,6 +180,7 @@ def test_persistent_x4_tail_is_the_one_tile_kernel(sh, weights7, B, h, w):
     finally:
         os.environ.pop("SR_NO_PERSIST_UP2", None)
         os.environ.pop("SR_SPLIT_TRUNK", None)
+        os.environ.pop("SR_TAIL", None)
     assert np.array_equal(outs[0], outs[1])
     want, _ = rt.generator_step(weights7, lr_t, lr_tm1, est)
     assert np.abs(outs[0] - want).max() <= FP32_TOL
@@ -186,7 +188,7 @@ def test_persistent_x4_tail_is_the_one_tile_kernel(sh, weights7, B, h, w):
 
 @pytest.mark.parametrize("B,h,w", [(2, 24, 40), (1, 8, 72), (3, 16, 8), (1, 96, 144), (5, 8, 8), (1, 40, 136), (2, 8, 16)])
 def test_plane_major_x4_tail(sh, weights7, B, h, w):
-    """conv_tail.hip's tail_kernel (SR_TAIL=1: conv2d_transpose_2 + conv2d_36 plane-major on 16 x 64 output tiles, two-pass tap
+    """conv_tail.hip's tail_kernel (the default; SR_TAIL=0 = the tap-major kernel: conv2d_transpose_2 + conv2d_36 plane-major on 16 x 64 output tiles, two-pass tap
     sum) against the tap-major kernel and the oracle.  The same products summed in another order: a few ulp between the kernels,
     the fp32 bar against the oracle.  Shapes: ragged right / bottom edges (4w = 32, 160, 288, 544, 576 columns on 64-column tiles,
     2h = 16, 32, 48, 80 rows on 8-row input tiles), several images, more tiles than workgroups."""
