@@ -155,7 +155,6 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(const TailArgs a) {
     };
     float* const PT = reinterpret_cast<float*>(smem + TL::OFF_REC);
     const unsigned char* const pwl = smem + TL::OFF_F + lane * 16;
-    const bool relu = a.act == A_RELU;
 
     for (;;) {
         const int tn = t + nslots;
@@ -173,6 +172,40 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(const TailArgs a) {
                     for (int j = 0; j < 4; ++j) acc[pq][n][4 * g + j] = b4[j];
             }
 
+        // conv2d_36's tap projection: p[4 g + j] = P[pixel r][column 8 g + 4 h + j] (column = tap * 3 + channel) per parity; K = the
+        // 64 activations of the pixel in the accumulators' own order (the host permutes the packed matrix to match).  One step =
+        // 16 channels (half n, group pair s): ReLU, hi / lo split (VALU), three MFMAs.
+        f32x16 pk[4];
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pk[pq][i] = 0.f;
+        auto proj_step = [&](int pq, int kidx) {
+            if (DBG & 2) {
+                if (kidx == 0) pk[pq] = acc[pq][0] + acc[pq][1];
+                return;
+            }
+            const int n = kidx >> 1, s2 = kidx & 1;
+            u32x4 xh4, xl4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i0 = 8 * s2 + 2 * e;      // k index 2e, 2e + 1 of step (n, s) = accumulator registers 8s + 2e, + 1
+                float v0 = acc[pq][n][i0], v1 = acc[pq][n][i0 + 1];
+                // ReLU as ONE instruction: fmaxf() costs a canonicalising v_max in front of the v_max (accumulators may hold any bits)
+                asm("v_max_f32 %0, 0, %1" : "=v"(v0) : "v"(v0));
+                asm("v_max_f32 %0, 0, %1" : "=v"(v1) : "v"(v1));
+                const unsigned hi = pack_bf16_2(v0, v1);
+                xh4[e] = hi;
+                xl4[e] = pack_bf16_2(v0 - __builtin_bit_cast(float, hi << 16), v1 - __builtin_bit_cast(float, hi & 0xFFFF0000u));
+            }
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pwl + (kidx * 2 + 0) * 1024));
+            const bf16x8 wl2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pwl + (kidx * 2 + 1) * 1024));
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, xh4), xl = __builtin_bit_cast(bf16x8, xl4);
+            pk[pq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, pk[pq], 0, 0, 0);
+            pk[pq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl2, xh, pk[pq], 0, 0, 0);
+            pk[pq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, pk[pq], 0, 0, 0);
+        };
+
         auto plane_step = [&](auto cc) {
             constexpr int C = decltype(cc)::value;
             // this plane's tile and weights have landed (everything this wave issued is done; the barrier covers the other waves),
@@ -188,11 +221,10 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(const TailArgs a) {
             }
             const unsigned char* at = smem + ((C & 1) ? TL::OFF_A1 : TL::OFF_A0);
             const unsigned char* bw = smem + ((C & 1) ? TL::OFF_W1 : TL::OFF_W0) + lane * 16;
-            // tap order: the four taps of shift (0, 0) first, then shift (0, 1), (1, 0), (1, 1);
-            // tap (ky, kx) = shift (ky >> 1, kx >> 1), parity 2 (ky & 1) + (kx & 1)
+            // tap (ky, kx) = shift (ky >> 1, kx >> 1), parity 2 (ky & 1) + (kx & 1); the four taps of shift (0, 0) first, then shift
+            // (0, 1), (1, 0), (1, 1): two shifts' pixel fragments live at a time, shift s in buffer s & 1, read two taps before its first use
             constexpr int order[9] = {0, 1, 3, 4, 2, 5, 6, 7, 8};
-            // half-tap pipeline: step m = (tap order[m >> 1], channel half m & 1) = 3 MFMAs; its two weight fragments are read one
-            // step ahead, the pixel fragments of a shift two taps before its first use (two shifts live at a time)
+            // half-tap pipeline: step m = (tap order[m >> 1], channel half m & 1) = 3 MFMAs; its two weight fragments are read one step ahead
             u32x4 xs[2][2], wf[2][2];      // [shift & 1][hi, lo]; [m & 1][hi, lo]
             auto load_x = [&](int sft) {
                 const int ad = x_addr(sft >> 1, sft & 1);
@@ -234,46 +266,13 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(const TailArgs a) {
         plane_step(std::integral_constant<int, 1>{});
         plane_step(std::integral_constant<int, 2>{});
         plane_step(std::integral_constant<int, 3>{});
-
-        // ---- conv2d_36's tap projection: p[4 g + j] = P[pixel r][column 8 g + 4 h + j] (column = tap * 3 + channel) per parity;
-        // K = the 64 activations of the pixel in the accumulators' own order (the host permutes the packed matrix to match)
-        f32x16 pk[4];
+        // (Tried: the last plane's taps parity by parity and the finished parities' projection steps inside the MFMA stream of its
+        // remaining taps -- the schedule came out as written, the time did not change: the phase is VALU-bound, 32 instructions per
+        // 3 MFMAs, and stays so wherever it runs.)
 #pragma unroll
-        for (int pq = 0; pq < 4; ++pq) {
-            if (DBG & 2) {
-                pk[pq] = acc[pq][0] + acc[pq][1];
-                continue;
-            }
-            f32x16 p;
+        for (int pq = 0; pq < 4; ++pq)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) p[i] = 0.f;
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    u32x4 xh4, xl4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i0 = 8 * s + 2 * e;      // k index 2e, 2e + 1 of step (n, s) = accumulator registers 8s + 2e, + 1
-                        float v0 = acc[pq][n][i0], v1 = acc[pq][n][i0 + 1];
-                        if (relu) {
-                            v0 = fmaxf(v0, 0.f);
-                            v1 = fmaxf(v1, 0.f);
-                        }
-                        const unsigned hi = pack_bf16_2(v0, v1);
-                        xh4[e] = hi;
-                        xl4[e] = pack_bf16_2(v0 - __builtin_bit_cast(float, hi << 16), v1 - __builtin_bit_cast(float, hi & 0xFFFF0000u));
-                    }
-                    const int kidx = n * 2 + s;
-                    const bf16x8 wh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pwl + (kidx * 2 + 0) * 1024));
-                    const bf16x8 wl2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pwl + (kidx * 2 + 1) * 1024));
-                    const bf16x8 xh = __builtin_bit_cast(bf16x8, xh4), xl = __builtin_bit_cast(bf16x8, xl4);
-                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, p, 0, 0, 0);
-                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl2, xh, p, 0, 0, 0);
-                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, p, 0, 0, 0);
-                }
-            pk[pq] = p;
-        }
+            for (int kidx = 0; kidx < 4; ++kidx) proj_step(pq, kidx);
 
         // ---- the nine-tap sum over the 16 x 64 output tile, two passes of nine record rows (rows 0..8, then rows 7..15)
         // the thread index passes through an opaque copy per tile: otherwise every lane-constant address of this phase is hoisted
@@ -424,7 +423,7 @@ hipError_t launch_tail(TailArgs a, hipStream_t s) {
     if (a.B < 1 || a.H < 1 || a.W < 1 || !a.in || !a.wpack || !a.bias || !a.proj_w || !a.gbias || !a.img || !a.S) return hipErrorInvalidValue;
     if (a.gather_cout < 1 || a.gather_cout > 3 || a.gather_cs < a.gather_cout) return hipErrorInvalidValue;
     if (a.gather_act != A_NONE && a.gather_act != A_RELU && a.gather_act != A_CLIP01) return hipErrorInvalidValue;
-    if (a.act != A_RELU && a.act != A_NONE) return hipErrorInvalidValue;
+    if (a.act != A_RELU) return hipErrorInvalidValue;      // the only activation between the two layers (reference layers.py:74)
     // 32-bit offsets: the tensor and the zero bytes behind it
     if ((double)a.B * a.H * a.W * 256.0 + 4096.0 > 4294967295.0 || (double)a.zero_off + 4096.0 > 4294967295.0) return hipErrorInvalidValue;
     a.tiles_x = (a.W + TL::TWX - 1) / TL::TWX;
