@@ -178,14 +178,16 @@ __global__ __launch_bounds__(256) void pre_srnet_kernel(const float* __restrict_
                                                         const float* __restrict__ lr, T* __restrict__ out,
                                                         float* __restrict__ hr_out, int B, int H, int W) {
     __shared__ __attribute__((aligned(16))) float rows[64][64 + 4];
-    const long npix = (long)B * H * W;
+    // 32-bit pixel indices (the launcher refuses B*H*W >= 2^31): 64-bit divisions and address products were a third of the kernel's
+    // instructions, and at 700 instructions per thread the kernel was issue-bound, not HBM-bound
+    const unsigned npix = (unsigned)B * (unsigned)H * (unsigned)W;
     const int lp = threadIdx.x >> 2, dy = threadIdx.x & 3;
-    const long p = (long)blockIdx.x * 64 + lp;
+    const unsigned p = blockIdx.x * 64u + (unsigned)lp;
     if (p < npix) {
-        const int x = p % W;
-        long q = p / W;
-        const int y = q % H;
-        const int b = q / H;
+        const unsigned q = p / (unsigned)W;
+        const int x = (int)(p - q * (unsigned)W);
+        const int b = (int)(q / (unsigned)H);
+        const int y = (int)(q - (unsigned)b * (unsigned)H);
         const int x1 = min(x + 1, W - 1), y1 = min(y + 1, H - 1);
         const float* fb = flow + (size_t)b * H * W * 2;
         const float2 ftl = *reinterpret_cast<const float2*>(fb + ((size_t)y * W + x) * 2);
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void pre_srnet_kernel(const float* __restrict_
         for (int i = 0; i < 12; ++i) rows[lp][3 + dy * 12 + i] = vals[i];
         if (dy == 0) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) rows[lp][c] = lr[p * 3 + c];
+            for (int c = 0; c < 3; ++c) rows[lp][c] = lr[(size_t)p * 3 + c];
         } else if (dy == 1) {
 #pragma unroll
             for (int c = 51; c < 64; ++c) rows[lp][c] = 0.f;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256) void pre_srnet_kernel(const float* __restrict_
         const size_t hw = (size_t)H * W;
         for (int v = threadIdx.x; v < 1024; v += 256) {
             const int plane = v >> 8, row = (v >> 2) & 63, u = v & 3;
-            const long pp = (long)blockIdx.x * 64 + row;
+            const unsigned pp = blockIdx.x * 64u + (unsigned)row;
             if (pp < npix) {
                 const int hh = u >> 1;
                 typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
@@ -246,7 +248,8 @@ __global__ __launch_bounds__(256) void pre_srnet_kernel(const float* __restrict_
                     const __bf16 hi = (__bf16)f;
                     o[e] = (u & 1) ? (__bf16)(f - (float)hi) : hi;
                 }
-                const size_t b = (size_t)(pp / (long)hw), pix = (size_t)pp - b * hw;
+                const unsigned bb = pp / (unsigned)hw;
+                const size_t b = bb, pix = pp - bb * (unsigned)hw;
                 unsigned char* dst = reinterpret_cast<unsigned char*>(out) + ((b * 4 + plane) * hw + pix) * 64 + u * 16;
                 *reinterpret_cast<bf16x8v*>(dst) = o;
             }
@@ -258,12 +261,12 @@ __global__ __launch_bounds__(256) void pre_srnet_kernel(const float* __restrict_
     constexpr int VPR = 64 / N;               // vectors per row
     for (int v = threadIdx.x; v < 64 * VPR; v += 256) {
         const int row = v / VPR, part = v % VPR;
-        const long pp = (long)blockIdx.x * 64 + row;
+        const unsigned pp = blockIdx.x * 64u + (unsigned)row;
         if (pp < npix) {
             Vec<T> w;
 #pragma unroll
             for (int i = 0; i < N; ++i) w.set(i, rows[row][part * N + i]);
-            reinterpret_cast<Vec<T>*>(out + pp * 64)[part] = w;
+            reinterpret_cast<Vec<T>*>(out + (size_t)pp * 64)[part] = w;
         }
     }
 }
@@ -271,6 +274,7 @@ __global__ __launch_bounds__(256) void pre_srnet_kernel(const float* __restrict_
 hipError_t launch_pre_srnet(const float* flow, const float* est_prev, const float* lr_t, void* out,
                             float* hr_warp_out, int act_bf16, int B, int H, int W, hipStream_t s) {
     const long npix = (long)B * H * W;
+    if (npix >= 0x7fffffffL) return hipErrorInvalidValue;      // the kernel indexes pixels with 32 bits
     const dim3 grid(blocks_for(npix, 64)), block(256);
     if (act_bf16 == 2) {
         if (hr_warp_out) hipLaunchKernelGGL((pre_srnet_kernel<float, true, true>), grid, block, 0, s, flow, est_prev, lr_t, (float*)out, hr_warp_out, B, H, W);
