@@ -315,7 +315,11 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(const TailArgs a) {
             float* op = a.img + (((size_t)b * Ho + gy) * Wo + gx) * a.gather_cs;
 #pragma unroll
             for (int co = 0; co < 3; ++co)
-                if (co < a.gather_cout) op[co] = fminf(fmaxf(o[co], lo_c), hi_c);
+                if (co < a.gather_cout) {
+                    const float v = fminf(fmaxf(o[co], lo_c), hi_c);
+                    if (DBG & 32) asm volatile("" ::"v"(v));      // ablation: no image stores
+                    else op[co] = v;
+                }
         };
         // Pixel of the tile's outermost ring or of the ring around the tile (ly = -1 / 16, lx = -1 / 64): the partial sum over THIS
         // tile's records goes to S[k], k = 2 (vertical neighbour's pixel) + (horizontal neighbour's pixel); gather_fix_kernel adds.
@@ -437,6 +441,7 @@ hipError_t launch_tail(TailArgs a, hipStream_t s) {
     if (dbg == 8) return launch_tail_t<8>(a, 8 * nslots, s);
     if (dbg == 16) return launch_tail_t<16>(a, 8 * nslots, s);
     if (dbg == 24) return launch_tail_t<24>(a, 8 * nslots, s);
+    if (dbg == 32) return launch_tail_t<32>(a, 8 * nslots, s);
     switch (dbg & 7) {
         case 0: return launch_tail_t<0>(a, 8 * nslots, s);
         case 1: return launch_tail_t<1>(a, 8 * nslots, s);

@@ -46,11 +46,18 @@ def oracle_frames(weights7, bench_clips):
     return rt.run_clip(weights7, bench_clips[:, list(CHECKED)])
 
 
-@pytest.mark.parametrize("dtype,tol,psnr_tol", [("fp32", 1e-3, 0.01), ("bf16x3", 1e-3, 0.01), ("bf16", 0.15, 0.5)])
-def test_bench_configuration_every_frame(sh, weights7, bench_clips, oracle_frames, dtype, tol, psnr_tol):
+@pytest.mark.parametrize("dtype,tol,psnr_tol,env", [("fp32", 1e-3, 0.01, {}), ("bf16x3", 1e-3, 0.01, {}), ("bf16", 0.15, 0.5, {}),
+                                                    ("bf16x3", 1e-3, 0.01, {"SR_TAIL": "0"})])
+def test_bench_configuration_every_frame(sh, weights7, bench_clips, oracle_frames, dtype, tol, psnr_tol, env):
+    """env SR_TAIL=0: the x4 tail on the tap-major kernels (conv_mfma.hip) instead of conv_tail.hip's plane-major one."""
     hr = np.stack([rn.synth_clip(c, FRAMES, 4 * H, 4 * W, scale=4) for c in CHECKED], axis=1)   # common PSNR target
-    ctx = sh.Context(HP, W, max_batch=CLIPS, dtype=dtype)
-    ctx.load_weights(weights7)
+    os.environ.update(env)
+    try:
+        ctx = sh.Context(HP, W, max_batch=CLIPS, dtype=dtype)
+        ctx.load_weights(weights7)
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
     ctx.clip_begin(CLIPS)
     errs, dps = [], []
     for t in range(FRAMES):
@@ -60,7 +67,7 @@ def test_bench_configuration_every_frame(sh, weights7, bench_clips, oracle_frame
             a, b = out[i, :4 * H], oracle_frames[t, i, :4 * H]
             dps.append(abs(rn.psnr(a, hr[t, i]) - rn.psnr(b, hr[t, i])))
     ctx.close()
-    print(f"\n[{dtype}] 184x320 B=16 per-frame max-abs err: {['%.2e' % e for e in errs]}  max PSNR delta {max(dps):.4f} dB")
+    print(f"\n[{dtype} {env}] 184x320 B=16 per-frame max-abs err: {['%.2e' % e for e in errs]}  max PSNR delta {max(dps):.4f} dB")
     assert max(errs) <= tol
     assert max(dps) <= psnr_tol
 
