@@ -191,9 +191,12 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(const TailArgs a) {
             for (int e = 0; e < 4; ++e) {
                 const int i0 = 8 * s2 + 2 * e;      // k index 2e, 2e + 1 of step (n, s) = accumulator registers 8s + 2e, + 1
                 float v0 = acc[pq][n][i0], v1 = acc[pq][n][i0 + 1];
-                // ReLU as ONE instruction: fmaxf() costs a canonicalising v_max in front of the v_max (accumulators may hold any bits)
-                asm("v_max_f32 %0, 0, %1" : "=v"(v0) : "v"(v0));
-                asm("v_max_f32 %0, 0, %1" : "=v"(v1) : "v"(v1));
+                // ReLU as ONE instruction: fmaxf() costs a canonicalising v_max in front of the v_max (accumulators may hold any
+                // bits); the med3 builtin compiles to a single v_max.  (NOT inline asm: hipcc does not see an asm's registers when
+                // it spaces VALU instructions from the MFMAs around them -- a build with this phase inside wave-conditional branches
+                // computed wrong projections for some waves with `asm("v_max_f32 ...")` and right ones with the builtin.)
+                v0 = __builtin_amdgcn_fmed3f(v0, 0.f, __builtin_inff());
+                v1 = __builtin_amdgcn_fmed3f(v1, 0.f, __builtin_inff());
                 const unsigned hi = pack_bf16_2(v0, v1);
                 xh4[e] = hi;
                 xl4[e] = pack_bf16_2(v0 - __builtin_bit_cast(float, hi << 16), v1 - __builtin_bit_cast(float, hi & 0xFFFF0000u));
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void tail_kernel(const TailArgs a) {
             }
         };
         auto bar = [&]() {
-            __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's LDS traffic is done
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS traffic is done (and no access moves across)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         };

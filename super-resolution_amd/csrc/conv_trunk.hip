@@ -211,9 +211,10 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
         if (RES && !(NOMEM & 4)) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(pc.rh), "+v"(pc.rl) : "n"(N));
     };
     auto ep_pair = [&](Piece& pc, float v0, float v1, int k) {
-        if (RELU) {      // one v_max each: fmaxf() puts a canonicalising v_max in front (the accumulators may hold any bits)
-            asm("v_max_f32 %0, 0, %1" : "=v"(v0) : "v"(v0));
-            asm("v_max_f32 %0, 0, %1" : "=v"(v1) : "v"(v1));
+        if (RELU) {      // one v_max each (fmaxf() puts a canonicalising v_max in front: the accumulators may hold any bits); the
+                         // builtin, not inline asm: hipcc keeps VALU instructions clear of in-flight MFMAs only for what it can see
+            v0 = __builtin_amdgcn_fmed3f(v0, 0.f, __builtin_inff());
+            v1 = __builtin_amdgcn_fmed3f(v1, 0.f, __builtin_inff());
         }
         if (RES) {
             v0 += bf_even(pc.rh[k]) + bf_even(pc.rl[k]);
@@ -492,8 +493,8 @@ __global__ __launch_bounds__(512, 2) void trunk_convT_kernel(const TrunkArgs a) 
     asm volatile("" : "+v"(sw[0]), "+v"(sw[1]), "+v"(sw[2]), "+v"(sw[3]), "+v"(sr4[0]), "+v"(sr4[1]), "+v"(sr4[2]), "+v"(sr4[3]));
 
     auto ep_pair = [&](float v0, float v1, u32x4& oh, u32x4& ol, int k) {
-        asm("v_max_f32 %0, 0, %1" : "=v"(v0) : "v"(v0));      // ReLU, one instruction (see trunk_conv_kernel)
-        asm("v_max_f32 %0, 0, %1" : "=v"(v1) : "v"(v1));
+        v0 = __builtin_amdgcn_fmed3f(v0, 0.f, __builtin_inff());      // ReLU, one instruction (see trunk_conv_kernel)
+        v1 = __builtin_amdgcn_fmed3f(v1, 0.f, __builtin_inff());
         const unsigned hi = pack_bf16(v0, v1);
         oh[k] = hi;
         ol[k] = pack_bf16(v0 - bf_even(hi), v1 - bf_odd(hi));
