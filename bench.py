@@ -119,29 +119,48 @@ def kernel_profile(torch, ctx, lr_dev, steps):
     return prof
 
 
-def pmc_traffic(dtype):
-    """HBM bytes per launch of the res-block conv from the committed PMC passes (counters need
-    their own rocprofv3 runs, so they cannot be read live here); None when no pass is on file."""
-    for name in ("r2_hbm_traffic.json", "r1_hbm_traffic.json"):
-        try:
-            d = json.load(open(os.path.join(ROOT, "profiles", name)))
-            tag = d.get("trunk_kernel", {}).get(dtype) or {
-                "bf16x3": "conv3x3_lds_kernel<2, 2, 1, true>", "bf16": "conv3x3_lds_kernel<1, 2, 2, true>",
-                "fp32": "conv3x3_lds_kernel<0, 2, 2, true>"}[dtype]
-            tags = tag if isinstance(tag, list) else [tag]
-            found = []
-            for t in tags:
-                best = None
-                for k, v in d["kernels"].items():   # the trunk's grid is the one with the most launches
-                    if k.startswith(t) and (best is None or v["launches"] > best["launches"]):
-                        best = v
-                if best:
-                    found.append(best["hbm_bytes"])
-            if len(found) == len(tags):
-                return round(sum(found) / len(found)), name
-        except (OSError, KeyError, ValueError):
-            continue
-    return None, None
+# the kernels behind `srnet.res` per dtype, as rocprofv3 names them (prefix match; tools/pmc_summary.py writes the same map
+# into the traffic file as `trunk_kernel`).  bf16x3: the ReLU and the residual instantiation of conv_trunk.hip alternate,
+# the reported figure is their mean.
+TRUNK_KERNELS = {"bf16x3": ["trunk_conv_kernel<false, true, 0>", "trunk_conv_kernel<true, false, 0>"],
+                 "bf16": ["conv3x3_lds_kernel<1, 2, 2, true"], "fp32": ["conv3x3_lds_kernel<0, 2, 2, true"]}
+
+
+def newest_traffic_file(profiles_dir):
+    """profiles/rN_hbm_traffic.json with the largest N, or None."""
+    best = None
+    for f in os.listdir(profiles_dir) if os.path.isdir(profiles_dir) else []:
+        if f.startswith("r") and f.endswith("_hbm_traffic.json") and f[1:-len("_hbm_traffic.json")].isdigit():
+            n = int(f[1:-len("_hbm_traffic.json")])
+            if best is None or n > best[0]:
+                best = (n, f)
+    return best[1] if best else None
+
+
+def pmc_traffic(dtype, profiles_dir=None):
+    """HBM bytes per launch of the res-block conv from the NEWEST committed PMC pass (counters need their own
+    rocprofv3 runs, so they cannot be read live here).  Returns (bytes, file, note): bytes is None -- never an
+    older round's figure for another kernel -- when that file does not hold the kernels timed here."""
+    profiles_dir = profiles_dir or os.path.join(ROOT, "profiles")
+    name = newest_traffic_file(profiles_dir)
+    if not name:
+        return None, None, "no profiles/rN_hbm_traffic.json on file"
+    try:
+        d = json.load(open(os.path.join(profiles_dir, name)))
+        tags = d.get("trunk_kernel", {}).get(dtype) or TRUNK_KERNELS[dtype]
+        tags = tags if isinstance(tags, list) else [tags]
+        found = []
+        for t in tags:
+            best = None
+            for k, v in d["kernels"].items():   # the trunk's grid is the one with the most launches
+                if k.startswith(t) and (best is None or v["launches"] > best["launches"]):
+                    best = v
+            if best is None:
+                return None, name, f"{name} holds no kernel named {t}*"
+            found.append(best["hbm_bytes"])
+        return round(sum(found) / len(found)), name, f"mean over {len(found)} kernel(s): " + ", ".join(tags)
+    except (OSError, KeyError, ValueError) as e:
+        return None, name, f"{name}: {type(e).__name__}: {e}"
 
 
 def cpu_baseline(weights, lr0):
@@ -360,12 +379,18 @@ def main():
         alg_flops = RES_CONV_FLOP_PER_LR_PX * BATCH * H_LR * W_LR * round(convs_per_launch)   # credited on the unpadded 180 rows
         achieved = alg_flops / (avg_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
-        traffic, traffic_src = pmc_traffic(args.dtype)
+        traffic, traffic_src, traffic_note = pmc_traffic(args.dtype)
+        # algorithmic bytes per launch: 256 B in + 256 B out per LR pixel (64 channels x 4 B), + 256 B of residual on every
+        # second launch -- on the padded 184 rows the kernel really moves, like `traffic`
+        alg_bytes = round(BATCH * H_PAD * W_LR * 256 * 2.5 * round(convs_per_launch))
         out["roofline"] = {"bound": "mfma", "kernel": "srnet.res: the SRNet trunk's 64->64 3x3 convs "
                                                        f"({round(convs_per_launch)} conv(s) per launch, {res['launches'] // max(1, min(args.steps, 10))} launches/step)",
                            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(achieved / peak, 4), "traffic": traffic,
-                           "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, profiles/{traffic_src})",
+                           "frac": round(achieved / peak, 4), "traffic": traffic, "algorithmic_bytes": alg_bytes,
+                           "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
+                           "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, "
+                                           f"profiles/{traffic_src}); algorithmic_bytes = mean of ReLU (512 B/px) and residual (768 B/px) launches",
+                           "traffic_note": traffic_note,
                            "avg_launch_ms": round(avg_ms, 4), "launches_timed": res["launches"]}
         nsteps_prof = max(2, min(args.steps, 10))
         tot = sum(p["ms_total"] for p in prof)

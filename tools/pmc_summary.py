@@ -80,6 +80,13 @@ def main():
         wk, _ = write.get(k, (0.0, 0))
         out["kernels"][k] = {"launches": n, "fetch_bytes": round(fk * 1024 * 2), "write_bytes": round(wk * 1024),
                              "hbm_bytes": round(fk * 1024 * 2 + wk * 1024)}
+    # the kernels behind bench.py's roofline line (`srnet.res`), so that the bench and this file cannot drift apart
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    try:
+        from bench import TRUNK_KERNELS
+        out["trunk_kernel"] = {d: t for d, t in TRUNK_KERNELS.items() if all(any(k.startswith(x) for k in out["kernels"]) for x in t)}
+    except ImportError:
+        pass
     json.dump(out, open(sys.argv[4], "w"), indent=1)
     print(json.dumps(out, indent=1))
 
