@@ -316,7 +316,10 @@ int sr_tecogan_iteration(sr_ctx* ctx, sr_disc* d, int B, const float* const* arr
  * slice plan keeps that near 19 MB for any image size while Cin x Cout <= 2048 x 1024 or so (every layer of
  * this network fits at any batch; 2048 -> 2048 channels would need 152 MB and is refused).  Every call on a GPU shares that GPU's array: calls that overlap on one
  * GPU (different streams or threads) race; calls on one stream are safe back to back.  It calls no hipMalloc /
- * hipFree; the first call on a device only looks up the array's address (hipGetSymbolAddress). */
+ * hipFree; the first call on a device only looks up the array's address (hipGetSymbolAddress) -- a lookup that
+ * is not allowed inside a stream capture, so a caller that captures makes one warm-up call per device (any valid
+ * shape) BEFORE it begins capturing.  `device` need not be the caller's current device: the call switches to it
+ * and restores the caller's current device before it returns, on every path. */
 #define SR_NOALLOC_SCRATCH_BYTES (32 * 1024 * 1024)
 int sr_op_conv3x3_wgrad_noalloc(int device, int dtype, int B, int H, int W, int Cin, int Cout, const float* d_x,
                                 const float* d_dy, float* d_dw, float* d_db, void* hip_stream);

@@ -56,7 +56,22 @@ extern "C" int sr_op_conv3x3_wgrad_noalloc(int device, int dtype, int B, int H, 
         return fail(nullptr, SR_ERR_ARG, "sr_op_conv3x3_wgrad_noalloc: this shape needs %zu bytes of slice partials, the static "
                     "scratch holds %d; use sr_op_conv3x3_bwd (which allocates) or a smaller batch", need,
                     (int)SR_NOALLOC_SCRATCH_BYTES);
-    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, SR_ERR_HIP, "hipSetDevice failed");
+    // the caller's current device is restored on every exit path (a multi-GPU caller passing device != current must not
+    // find its later HIP calls redirected)
+    struct DeviceGuard {
+        int prev = -1;
+        ~DeviceGuard() {
+            if (prev >= 0) (void)hipSetDevice(prev);
+        }
+    } guard;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return fail(nullptr, SR_ERR_HIP, "hipGetDevice failed");
+    if (cur != device) {
+        if (hipSetDevice(device) != hipSuccess) return fail(nullptr, SR_ERR_HIP, "hipSetDevice failed");
+        guard.prev = cur;
+    }
+    // first call on a device: hipGetSymbolAddress -- not legal inside a stream capture, so a capturing caller makes one
+    // call per device (any valid shape) before it starts capturing; see include/sr_hip.h
     unsigned char* ptr = nullptr;
     if (int rc = scratch_ptr(device, &ptr)) return rc;
     // every slice partial the reduction reads is written by this launch's first kernel, so nothing has to be

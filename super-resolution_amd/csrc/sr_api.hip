@@ -405,8 +405,13 @@ int alloc_buf(sr_ctx* c, const char* name, size_t bytes) {
 }
 
 // split-planar trunk (conv_trunk.hip) for this step?
+// The split-planar kernels address their tensors -- and the zero / dump tail behind image max_batch - 1 -- with 32-bit byte
+// offsets from the lane's first image, so the largest of them ("up1": 1 KiB per LR pixel) bounds the ctx: beyond
+// max_batch * h * w * 1024 + 4 KiB = 4 GiB (max_batch 71 at 184x320) every step takes the generic conv_mfma path instead
+// (64-bit addressing), whatever B is.
 bool use_split(const sr_ctx* c, int B) {
     if (c->prec != P_BF16X3 || !c->split_trunk || !c->srnet[0].d_w2) return false;
+    if ((double)c->max_batch * c->h * c->w * 1024.0 + 4096.0 > 4294967295.0) return false;
     return c->split_trunk >= 2 || (size_t)B * c->h * c->w > 65536;
 }
 
@@ -751,6 +756,21 @@ int get_out(sr_ctx* c, float* dst, bool dst_dev, const float* d_src, int B, int 
     return SR_OK;
 }
 
+// the uint8 output path's lazily made objects (sr_clip_push_u8); also the cleanup of a partially failed first use
+void free_u8_path(sr_ctx* c) {
+    for (int i = 0; i < 2; ++i) {
+        if (c->d_u8[i]) (void)hipFree(c->d_u8[i]);
+        if (c->ev_u8_ready[i]) (void)hipEventDestroy(c->ev_u8_ready[i]);
+        if (c->ev_u8_done[i]) (void)hipEventDestroy(c->ev_u8_done[i]);
+        c->d_u8[i] = nullptr;
+        c->ev_u8_ready[i] = c->ev_u8_done[i] = nullptr;
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    c->copy_stream = nullptr;
+    c->u8_ready = false;
+    c->u8_pushes = 0;
+}
+
 }  // namespace srh
 
 using namespace srh;
@@ -873,15 +893,8 @@ int sr_destroy(sr_ctx* c) {
                    c->d_io_lr, c->d_io_hr};
     for (auto p : fl)
         if (p) (void)hipFree(p);
-    if (c->copy_stream) {
-        (void)hipStreamSynchronize(c->copy_stream);
-        (void)hipStreamDestroy(c->copy_stream);
-    }
-    for (int i = 0; i < 2; ++i) {
-        if (c->d_u8[i]) (void)hipFree(c->d_u8[i]);
-        if (c->ev_u8_ready[i]) (void)hipEventDestroy(c->ev_u8_ready[i]);
-        if (c->ev_u8_done[i]) (void)hipEventDestroy(c->ev_u8_done[i]);
-    }
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    free_u8_path(c);
     for (auto& L : c->fnet) free_layer(L);
     for (auto& L : c->srnet) free_layer(L);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1098,16 +1111,21 @@ int sr_clip_push_u8(sr_ctx* c, const float* lr_t, int lr_on_device, uint8_t* est
     if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
     if (!est_u8_host) return fail(c, SR_ERR_ARG, "est_u8_host is NULL");
     HIPCHK(c, hipSetDevice(c->device));
-    if (!c->copy_stream) {   // first use: the copy stream, two device frames and their events
+    if (!c->clip_active) return fail(c, SR_ERR_STATE, "sr_clip_push_u8 without sr_clip_begin");   // before anything is allocated
+    if (!c->u8_ready) {   // first use: the copy stream, two device frames and their events; ready only when ALL of them exist
         const size_t n = (size_t)c->max_batch * 16 * c->h_in * c->w_in * 3;
         bool ok = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
         for (int i = 0; i < 2 && ok; ++i)
             ok = hipMalloc((void**)&c->d_u8[i], n) == hipSuccess &&
                  hipEventCreateWithFlags(&c->ev_u8_ready[i], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&c->ev_u8_done[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) return fail(c, SR_ERR_HIP, "uint8 output path: stream / buffer / event creation failed");
+        if (!ok) {   // leave nothing half made: the next call starts over
+            (void)hipGetLastError();
+            free_u8_path(c);
+            return fail(c, SR_ERR_HIP, "uint8 output path: stream / buffer / event creation failed");
+        }
+        c->u8_ready = true;
     }
-    if (!c->clip_active) return fail(c, SR_ERR_STATE, "sr_clip_push_u8 without sr_clip_begin");
     int rc = clip_push_common(c, lr_t, nullptr, lr_on_device != 0, false);   // no fp32 copy out, no synchronisation
     if (rc) return rc;
     const int B = c->clip_B, slot = (int)(c->u8_pushes & 1);

@@ -79,6 +79,7 @@ struct sr_ctx {
     unsigned char* d_u8[2] = {nullptr, nullptr};
     hipEvent_t ev_u8_ready[2] = {nullptr, nullptr}, ev_u8_done[2] = {nullptr, nullptr};
     int64_t u8_pushes = 0;
+    bool u8_ready = false;   // every object of the path exists (set last; a failed first use frees what it made)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
@@ -201,6 +202,7 @@ struct ConvIO {
 
 int run_conv(sr_ctx* c, int prec, hipStream_t st, const ConvLayer& L, int B, const ConvIO& io, const char* name);
 int check_ready(sr_ctx* c, int B);
+void free_u8_path(sr_ctx* c);
 // one generator step on device pointers (sr_api.hip); d_est_out / d_lr_warp / d_hr_warp may be nullptr
 int run_step(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, const float* d_est_prev, float* d_est_out,
              float* d_lr_warp, float* d_hr_warp, bool warp_only);

@@ -977,10 +977,16 @@ int sr_tecogan_iteration(sr_ctx* c, sr_disc* d, int B, const float* const* array
     DiscStreamSwap swap_guard(d, st);
     // arrays: 0 lr, 1 prev_lr, 2 hr, 3 prev_hr, 4 next_hr, 5 prev_hat_hr, 6 next_hat_hr, 7 est, 8 prev_est, 9 next_est,
     //         10 prev_hat_est, 11 next_hat_est, 12 bic, 13 prev_bic, 14 next_bic
-    if (d->it_buf.empty()) {
-        d->it_buf.assign(13, nullptr);
-        for (float*& p : d->it_buf)
-            if (hipMalloc((void**)&p, (size_t)d->max_batch * img) != hipSuccess) return fail(c, SR_ERR_HIP, "hipMalloc failed");
+    if (d->it_buf.empty()) {   // non-empty means ready: a partial failure frees what it made and leaves it empty
+        std::vector<float*> bufs(13, nullptr);
+        for (float*& p : bufs)
+            if (hipMalloc((void**)&p, (size_t)d->max_batch * img) != hipSuccess) {
+                (void)hipGetLastError();
+                for (float* q : bufs)
+                    if (q) (void)hipFree(q);
+                return fail(c, SR_ERR_HIP, "sr_tecogan_iteration: hipMalloc of the batch buffers failed");
+            }
+        d->it_buf.swap(bufs);
     }
     float** hb = d->it_buf.data();          // hb[i] = arrays[i + 2]
     HIPCHK(c, hipMemcpyAsync(c->d_lr_t, arrays[0], nlr, hipMemcpyHostToDevice, st));

@@ -436,6 +436,16 @@ def disc_weight_specs(hr_shape, first_conv=37):
     return specs
 
 
+def disc_layer_names(first_conv=37, first_input=12, concat=3, first_lrelu=14, activation=2):
+    """`layer_names` of Discriminator.save_weights as Keras 2.2.4 lists them (model.layers: the nine inputs, then the layers by
+    depth, reference layers.py:153-176), numbered as in a process that ran TecoGAN.build() up to the discriminator
+    (TecoGAN.py:31-60: 11 inputs, 2 concatenates, 13 LeakyReLUs, 1 Activation before it).  Only the order matters to Keras."""
+    names = [f"input_{first_input + i}" for i in range(9)] + [f"concatenate_{concat}", f"conv2d_{first_conv}", f"leaky_re_lu_{first_lrelu}"]
+    for k in range(4):
+        names += [f"conv2d_{first_conv + 1 + k}", f"batch_normalization_{k + 1}", f"leaky_re_lu_{first_lrelu + 1 + k}"]
+    return names + ["flatten_1", "dense_1", f"activation_{activation}"]
+
+
 class DiscriminatorModel(_Model):
     """9 HR images -> [probability (B,1), d_1..d_4] (reference layers.py:178-183).  predict runs BatchNormalization on the
     moving statistics, train_on_batch on the batch statistics (and moves the moving ones), like Keras."""
@@ -505,7 +515,7 @@ class DiscriminatorModel(_Model):
         self.set_weights([a for _, a in tensors])
 
     def save_weights(self, path):
-        weights_io.write_tensors(path, self.named_weights(), keep_layer_prefix=True)
+        weights_io.write_tensors(path, self.named_weights(), keep_layer_prefix=True, layer_order=disc_layer_names())
 
     # -- native object (lazy, sized by the largest batch seen)
     def native(self, batch):

@@ -60,9 +60,10 @@ def _local(name):
     return name.split("/", 1)[1] if "/" in name else name
 
 
-def write_tensors(path, tensors, weightless_layers=(), keep_layer_prefix=False):
+def write_tensors(path, tensors, weightless_layers=(), keep_layer_prefix=False, layer_order=None):
     """weightless_layers: names of extra top-level layers without weights (Keras lists every layer of the model in
     ``layer_names`` -- the inputs, Upscaling_0, Warp_1 ... -- each with an empty group).
+    layer_order: every top-level layer name in the model's own order (overrides weightless_layers first / weighted after).
     keep_layer_prefix: the model's layers are plain layers, not sub-models (the discriminator): Keras names the weight
     ``conv2d_37/kernel:0`` and stores it INSIDE the group ``conv2d_37``, i.e. at ``conv2d_37/conv2d_37/kernel:0``."""
     tensors = [(n, np.ascontiguousarray(a, np.float32)) for n, a in tensors]
@@ -76,10 +77,19 @@ def write_tensors(path, tensors, weightless_layers=(), keep_layer_prefix=False):
             np.savez(fh, **arrays)
         return
     if ext in (".h5", ".hdf5"):
-        groups = [str(g) for g in weightless_layers]
-        for n, _ in tensors:
-            if _group_of(n) not in groups:
-                groups.append(_group_of(n))
+        if layer_order is not None:           # the model's layers in Keras' own order, weighted and weightless interleaved
+            groups = [str(g) for g in layer_order]
+            missing = [_group_of(n) for n, _ in tensors if _group_of(n) not in groups]
+            if missing:
+                raise ValueError(f"layer_order lacks the weighted layers {sorted(set(missing))}")
+        else:
+            groups = [str(g) for g in weightless_layers]
+            for n, _ in tensors:
+                if _group_of(n) not in groups:
+                    groups.append(_group_of(n))
+        # a layer without weights: Keras 2.2.4 hands h5py an empty list, which h5py stores as an EMPTY float64 attribute
+        # (save_attributes_to_hdf5_group -> np.asarray([])); both back ends write exactly that
+        no_names = np.zeros((0,), np.float64)
         try:
             import h5py
         except ImportError:
@@ -88,7 +98,7 @@ def write_tensors(path, tensors, weightless_layers=(), keep_layer_prefix=False):
                               "keras_version": np.bytes_(b"2.2.4")}, "children": {}}
             for g in groups:
                 names = [_local(n) for n, _ in tensors if _group_of(n) == g]
-                node = {"attrs": {"weight_names": np.array([n.encode() for n in names])} if names else {}, "children": {}}
+                node = {"attrs": {"weight_names": np.array([n.encode() for n in names]) if names else no_names}, "children": {}}
                 for n, a in tensors:
                     if _group_of(n) != g:
                         continue
@@ -107,7 +117,7 @@ def write_tensors(path, tensors, weightless_layers=(), keep_layer_prefix=False):
             for g in groups:
                 lg = f.create_group(g)
                 names = [_local(n) for n, _ in tensors if _group_of(n) == g]
-                lg.attrs["weight_names"] = [n.encode() for n in names]
+                lg.attrs["weight_names"] = [n.encode() for n in names] if names else no_names
                 for n, a in tensors:
                     if _group_of(n) == g:
                         lg.create_dataset(_local(n), data=a)

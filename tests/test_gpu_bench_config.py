@@ -152,3 +152,26 @@ def test_split_planar_trunk_follows_training(sh, weights7):
     assert np.abs(a0 - b0).max() > 1e-3             # the steps moved the weights visibly
     assert np.abs(b2 - b0).max() <= 2e-4
     assert np.abs(a2 - a0).max() <= 2e-4
+
+
+def test_context_too_large_for_the_split_kernels_takes_the_generic_path(sh, weights7):
+    """the split-planar kernels address the zero / dump tail behind image max_batch - 1 with 32-bit
+    offsets, so a ctx with max_batch x h x w x 1 KiB >= 4 GiB (72 clips at 184x320) failed every bf16x3 step with 'tensor
+    too large for 32-bit offsets', whatever B.  Such a ctx now runs the generic 64-bit kernels; a small B on it equals the
+    same step on a small ctx (split path) to the two paths' usual distance."""
+    B = 2
+    lr_t, lr_tm1, est = step_inputs(4242, B, HP, W)
+
+    def run(max_batch):
+        ctx = sh.Context(HP, W, max_batch=max_batch, dtype="bf16x3")
+        ctx.load_weights(weights7)
+        out = ctx.step(lr_t, lr_tm1, est)
+        ctx.close()
+        return out
+
+    big, big_lw = run(72)          # 72 x 58,880 px x 1 KiB + 4 KiB > 4 GiB
+    small, small_lw = run(B)
+    assert np.abs(big - small).max() <= 2e-4
+    assert np.abs(big_lw - small_lw).max() <= 2e-4
+    want, _ = rt.generator_step(weights7, lr_t[:1], lr_tm1[:1], est[:1])
+    assert np.abs(big[:1] - want).max() <= 1e-3

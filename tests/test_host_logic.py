@@ -310,6 +310,14 @@ def test_discriminator_model_weights_and_files(tmp_path):
     with h5lite.File(str(tmp_path / 'd.h5'), 'r') as f:
         assert [x.decode() for x in f['conv2d_37'].attrs['weight_names']] == ['conv2d_37/kernel:0', 'conv2d_37/bias:0']
         assert f['conv2d_37']['conv2d_37/kernel:0'][()].shape == (3, 3, 27, 64)
+        # Keras lists EVERY layer of the model, in model.layers order, weightless ones with an empty weight_names
+        # attribute (h5py stores the empty list Keras hands it as an empty float64 array) -- ADVICE r2
+        names = [x.decode() for x in f.attrs['layer_names']]
+        assert names == layers.disc_layer_names() and len(names) == 27
+        assert names[:10] == [f'input_{i}' for i in range(12, 21)] + ['concatenate_3'] and names[-3:] == ['flatten_1', 'dense_1', 'activation_2']
+        for weightless in ('input_12', 'concatenate_3', 'leaky_re_lu_14', 'flatten_1', 'activation_2'):
+            wn = f[weightless].attrs['weight_names']
+            assert wn.shape == (0,) and wn.dtype == np.float64 and list(f[weightless].keys()) == []
     # a file written by a process that numbered its layers differently loads by position
     other = [(n.replace('conv2d_3', 'conv2d_').replace('conv2d_4', 'conv2d_1'), a + 1) for n, a in named]
     weights_io.write_tensors(str(tmp_path / 'e.npz'), other)
