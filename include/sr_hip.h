@@ -129,6 +129,17 @@ int sr_clip_push_dev(sr_ctx* ctx, const float* lr_t, float* est_t);
 int sr_clip_push_u8(sr_ctx* ctx, const float* lr_t, int lr_on_device, uint8_t* est_u8_host);
 int sr_u8_wait(sr_ctx* ctx, int keep_in_flight);
 
+/* The eval loop's metric frames (reference FRVSR.py:320-339: every 10th frame psnr / ssim read the float estimate
+ * predict returned, not the uint8 frame written to the video): copies the CURRENT estimates -- the state the last
+ * sr_clip_push* produced -- of clips first .. first + n - 1 to est (n,4h,4w,3) float32 on the host and returns when
+ * they have landed.  For drivers that take the frames as uint8 (sr_clip_push_u8) and need the float values of a few. */
+int sr_clip_read_est(sr_ctx* ctx, int first, int n, float* est);
+
+/* Page-locked host memory for the buffers sr_clip_push_u8 copies from / into asynchronously (Keras manages its own host
+ * staging inside predict; no reference counterpart).  bytes > 0; sr_host_free(NULL) is a no-op. */
+int sr_host_alloc(void** out, size_t bytes);
+int sr_host_free(void* p);
+
 /* Replaces fnet.predict (reference FRVSR.py:30, layers.py:15-49):
  * [I_LR_t, I_LR_t_1] (B,h,w,3) each -> flow (B,h,w,2). */
 int sr_fnet(sr_ctx* ctx, int B, const float* lr_t, const float* lr_tm1, float* flow);

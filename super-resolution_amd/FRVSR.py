@@ -227,7 +227,115 @@ class FrameRecurrentVideoSR(object):
                                        % (name, t, ms, p, q))
         return out, stats
 
+    def super_resolve_clips(self, lr_clips, hr_clips=None, names=None, metrics_file=None):
+        """The eval loop on SEVERAL clips in lock-step (what bench.py's `end_to_end` leg times):
+        clip k's rows x cols tiles are batch entries k*rows*cols .., one native step advances frame t of every clip, the
+        estimates leave the device as uint8 frames (the reference's denormalize, utils.py:60-62) through page-locked double
+        buffers -- the copy of frame t runs under the kernels of frame t+1 (sr_clip_push_u8) -- and every 10th frame the
+        float estimates are read back for PSNR / SSIM exactly as the reference computes them (FRVSR.py:320-339).  Clips of
+        unequal length finish independently (a finished clip's batch entries keep running on stale input, ignored).
+        lr_clips: list of [T_k, rows*h, cols*w, 3] float32; hr_clips: matching float32 HR clips or None.
+        Returns (list of uint8 [T_k, rows*4h, cols*4w, 3], list of stats dicts, timing dict)."""
+        rows = int(self.configs['data'].get('rows', 1))
+        cols = int(self.configs['data'].get('cols', 1))
+        h, w, _ = self.lr_shape
+        K, tiles = len(lr_clips), rows * cols
+        B = K * tiles
+        for c in lr_clips:
+            if c.shape[1:] != (rows * h, cols * w, 3):
+                raise ValueError(f'expected LR frames of shape {(rows * h, cols * w, 3)}, got {c.shape[1:]}')
+        names = list(names) if names is not None else ['clip%d' % k for k in range(K)]
+        Ts = [int(c.shape[0]) for c in lr_clips]
+        gen = self._generator()
+        ctx = gen.core.ctx(B)
+        # Page-locked staging.  When the whole group fits (eval.pinned_limit_mb, default 8192: T x B frames of LR float32 +
+        # uint8 estimates), every frame has its own slot: the LR tiles are staged before the loop (the reference's tiling
+        # is outside its inference bracket too, FRVSR.py:280-296) and the estimates land where they stay -- no host copy
+        # per step.  Otherwise two slots each: stage / consume frame by frame beside the GPU's work.
+        Tmax = max(Ts)
+        lr_bytes, out_bytes = B * h * w * 3 * 4, B * 16 * h * w * 3
+        limit = int(float(self.configs.get('eval', {}).get('pinned_limit_mb', 8192)) * (1 << 20))
+        slots = Tmax if Tmax * (lr_bytes + out_bytes) <= limit else 2
+        lr_pin = sr_hip.PinnedArray((slots, B, h, w, 3), np.float32)
+        out_pin = sr_hip.PinnedArray((slots, B, 4 * h, 4 * w, 3), np.uint8)
+        lr_pin.a[...] = 0
+        est_pin = sr_hip.PinnedArray((B, 4 * h, 4 * w, 3), np.float32) if hr_clips is not None else None   # metric frames
+        outs = [np.zeros((T, rows * 4 * h, cols * 4 * w, 3), np.uint8) for T in Ts]
+        for o in outs:
+            o.fill(0)            # touch the pages now, not inside the loop
+        stats = [{'psnr': [], 'ssim': [], 'bic_psnr': [], 'bic_ssim': [], 'ms': []} for _ in range(K)]
+        timing = {'frames': 0, 'loop_s': 0.0, 'metrics_s': 0.0, 'slots': slots}
+        now = datetime.datetime.now
+
+        def stage(t):            # LR tiles of frame t of every clip that has one
+            dst = lr_pin.a[t % slots]
+            for k in range(K):
+                if t < Ts[k]:
+                    dst[k * tiles:(k + 1) * tiles] = split_tiles(lr_clips[k][t], rows, cols, h, w)
+
+        def consume(t):          # frame t of every clip that has one has landed in out_pin[t % slots]
+            src = out_pin.a[t % slots]
+            for k in range(K):
+                if t < Ts[k]:
+                    outs[k][t] = merge_tiles(src[k * tiles:(k + 1) * tiles], rows, cols)
+
+        try:
+            if slots == Tmax:
+                for t in range(Tmax):
+                    stage(t)
+            ctx.clip_begin(B)        # zero state for prev LR tiles and prev estimates (reference FRVSR.py:233-234)
+            for t in range(Tmax):
+                t0 = now()
+                active = [k for k in range(K) if t < Ts[k]]
+                if slots != Tmax:
+                    stage(t)
+                ctx.clip_push_u8(lr_pin.ptr + (t % slots) * lr_bytes, out_pin.ptr + (t % slots) * out_bytes)
+                ctx.u8_wait(1)
+                if slots != Tmax and t > 0:
+                    consume(t - 1)
+                est_f = None
+                if t % 10 == 0 and hr_clips is not None:
+                    est_f = ctx.clip_read_est(0, B, out=est_pin.a)
+                ms = (now() - t0).total_seconds() * 1000
+                timing['loop_s'] += ms / 1000
+                timing['frames'] += len(active)
+                for k in active:
+                    stats[k]['ms'].append(ms / len(active))
+                if est_f is not None:
+                    t1 = now()
+                    for k in active:
+                        est = merge_tiles(est_f[k * tiles:(k + 1) * tiles], rows, cols)
+                        hr = hr_clips[k][t]
+                        p, q = psnr(hr, est), ssim(hr, est)
+                        stats[k]['psnr'].append(p)
+                        stats[k]['ssim'].append(q)
+                        bic = sr_hip.cubic_upscale4(lr_clips[k][t:t + 1], device=self.core.device)[0]   # FRVSR.py:304,322,328
+                        stats[k]['bic_psnr'].append(psnr(bic, hr))
+                        stats[k]['bic_ssim'].append(ssim(bic, hr))
+                        if metrics_file is not None:    # the reference's row (FRVSR.py:339)
+                            metrics_file.write('Video:\t%s\tFrame:\t%d\tInference time:\t%d\tPSNR:\t%f\tSSIM:\t%f\n'
+                                               % (names[k], t, ms / len(active), p, q))
+                    timing['metrics_s'] += (now() - t1).total_seconds()
+            t0 = now()
+            ctx.u8_wait(0)
+            timing['loop_s'] += (now() - t0).total_seconds()
+            if slots == Tmax:
+                for t in range(Tmax):
+                    consume(t)
+            else:
+                consume(Tmax - 1)
+        finally:
+            ctx.sync()
+            lr_pin.close()
+            out_pin.close()
+            if est_pin is not None:
+                est_pin.close()
+        return outs, stats, timing
+
     def eval(self):
+        """Reference FRVSR.py:205-376 on the rank's shard of the clips, `eval.clips_in_flight` (default 16) clips at a time
+        in lock-step (super_resolve_clips).  metrics.txt keeps the reference's rows and totals; the rows of one group are
+        written frame by frame, so clips of a group interleave (each row names its video)."""
         self._load_pretrained()
         out_dir = self.configs['eval']['output_dir']
         os.makedirs(out_dir, exist_ok=True)
@@ -238,37 +346,53 @@ class FrameRecurrentVideoSR(object):
         rows = int(self.configs['data'].get('rows', 1))
         cols = int(self.configs['data'].get('cols', 1))
         H, W = self.hr_shape[0] * rows, self.hr_shape[1] * cols
+        n_fly = max(1, int(self.configs['eval'].get('clips_in_flight', 16)))
+        synth = str(self.configs['data'].get('lr_synthesis', 'blur_cubic'))
         total, total_ssim, total_bic, total_bic_ssim, n = 0.0, 0.0, 0.0, 0.0, 0
+        frames, loop_s = 0, 0.0
         with open(os.path.join(out_dir, 'metrics.txt' if world == 1 else 'metrics_rank%d.txt' % rank), 'w+') as f:
-            for path in clips[lo:hi]:
-                clip = load_clip(path)
-                hr = normalize(clip) if clip.dtype == np.uint8 else clip.astype(np.float32)
-                if hr.shape[1:3] != (H, W):
-                    raise ValueError(f'{path}: frames are {hr.shape[1:3]}, the configured HR canvas is {(H, W)}')
-                # the reference's LR synthesis (FRVSR.py:274-277); data.lr_synthesis: box selects a plain average
-                synth = str(self.configs['data'].get('lr_synthesis', 'blur_cubic'))
-                if synth == 'box':
-                    lr = box_downscale(hr, 4)
-                elif synth == 'blur_cubic_host':
-                    lr = blur_cubic_downscale(hr)                         # numpy restatement
-                else:
-                    lr = sr_hip.blur_cubic_downscale(hr, device=self.core.device)   # same arithmetic, one fused GPU pass
-                est, stats = self.super_resolve_clip(lr, hr, os.path.basename(path), f)
-                np.save(os.path.join(out_dir, os.path.basename(path)), denormalize(est))
-                total += sum(stats['psnr'])
-                total_ssim += sum(stats['ssim'])
-                total_bic += sum(stats['bic_psnr'])
-                total_bic_ssim += sum(stats['bic_ssim'])
-                n += len(stats['psnr'])
+            mine = clips[lo:hi]
+            for g0 in range(0, len(mine), n_fly):
+                group = mine[g0:g0 + n_fly]
+                hrs, lrs = [], []
+                for path in group:
+                    clip = load_clip(path)
+                    hr = normalize(clip) if clip.dtype == np.uint8 else clip.astype(np.float32)
+                    if hr.shape[1:3] != (H, W):
+                        raise ValueError(f'{path}: frames are {hr.shape[1:3]}, the configured HR canvas is {(H, W)}')
+                    # the reference's LR synthesis (FRVSR.py:274-277); data.lr_synthesis: box selects a plain average
+                    if synth == 'box':
+                        lr = box_downscale(hr, 4)
+                    elif synth == 'blur_cubic_host':
+                        lr = blur_cubic_downscale(hr)                         # numpy restatement
+                    else:
+                        lr = sr_hip.blur_cubic_downscale(hr, device=self.core.device)   # same arithmetic, one fused GPU pass
+                    hrs.append(hr)
+                    lrs.append(lr)
+                names = [os.path.basename(p) for p in group]
+                ests, stats, timing = self.super_resolve_clips(lrs, hrs, names, f)
+                frames += timing['frames']
+                loop_s += timing['loop_s']
+                for path, est, st in zip(group, ests, stats):
+                    np.save(os.path.join(out_dir, os.path.basename(path)), est)
+                    total += sum(st['psnr'])
+                    total_ssim += sum(st['ssim'])
+                    total_bic += sum(st['bic_psnr'])
+                    total_bic_ssim += sum(st['bic_ssim'])
+                    n += len(st['psnr'])
+                    print('[INFO] %s: %d frames, FRVSR inference %.2f ms/frame, PSNR %.3f' % (
+                        os.path.basename(path), len(est), float(np.mean(st['ms'])),
+                        float(np.mean(st['psnr'])) if st['psnr'] else float('nan')))
                 f.write('\n')
-                print('[INFO] %s: %d frames, FRVSR inference %.2f ms/frame, PSNR %.3f' % (
-                    os.path.basename(path), len(est), float(np.mean(stats['ms'])),
-                    float(np.mean(stats['psnr'])) if stats['psnr'] else float('nan')))
+                print('[INFO] %d clips in lock-step: %d frames in %.3f s = %.1f frames/s (LR frames in, uint8 frames and the '
+                      'metric frames out; metrics %.3f s on the host beside it)'
+                      % (len(group), timing['frames'], timing['loop_s'], timing['frames'] / max(timing['loop_s'], 1e-9), timing['metrics_s']))
             mean_psnr = total / n if n else float('nan')
             mean_ssim = total_ssim / n if n else float('nan')
             f.write('Total PSNR:\t%f\tTotal SSIM:\t%f' % (mean_psnr, mean_ssim))    # FRVSR.py:368
             if n:                                                                     # FRVSR.py:369, typo included
                 f.write('Total bicubuc PSNR:\t%f\tTotal bicubic SSIM:\t%f' % (total_bic / n, total_bic_ssim / n))
                 print('\n[INFO] Avg. Bicubic PSNR: %f\tAvg. Bicubic SSIM: %f' % (total_bic / n, total_bic_ssim / n))
-        print('\n[INFO] Avg. FRVSR PSNR: %f\tAvg. FRVSR SSIM: %f' % (mean_psnr, mean_ssim))
+        self.eval_fps = frames / loop_s if loop_s > 0 else float('nan')
+        print('\n[INFO] Avg. FRVSR PSNR: %f\tAvg. FRVSR SSIM: %f\tInference: %.1f frames/s' % (mean_psnr, mean_ssim, self.eval_fps))
         return mean_psnr

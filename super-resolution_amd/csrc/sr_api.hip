@@ -1156,6 +1156,41 @@ int sr_u8_wait(sr_ctx* c, int keep_in_flight) {
     return SR_OK;
 }
 
+int sr_clip_read_est(sr_ctx* c, int first, int n, float* est) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    if (!c->clip_active) return fail(c, SR_ERR_STATE, "sr_clip_read_est without sr_clip_begin");
+    if (!est) return fail(c, SR_ERR_ARG, "est is NULL");
+    if (first < 0 || n < 1 || first + n > c->clip_B) return fail(c, SR_ERR_ARG, "clips [%d, %d) outside the clip batch of %d", first, first + n, c->clip_B);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t img = (size_t)c->h * c->w * 48;   // kernel-side image (padded ctx: get_out crops)
+    int rc = get_out(c, est, false, c->d_est[c->cur] + (size_t)first * img, n, 4, 3);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SR_OK;
+}
+
+int sr_host_alloc(void** out, size_t bytes) {
+    if (!out) return fail(nullptr, SR_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (bytes == 0) return fail(nullptr, SR_ERR_ARG, "sr_host_alloc of 0 bytes");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, SR_ERR_HIP, "no HIP device available; libsr_hip has no CPU fallback");
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        *out = nullptr;
+        return fail(nullptr, SR_ERR_HIP, "hipHostMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    }
+    return SR_OK;
+}
+
+int sr_host_free(void* p) {
+    if (!p) return SR_OK;
+    hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) return fail(nullptr, SR_ERR_HIP, "hipHostFree failed: %s", hipGetErrorString(e));
+    return SR_OK;
+}
+
 int sr_fnet(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, float* flow) {
     int rc = check_ready(c, B);
     if (rc) return rc;

@@ -42,6 +42,9 @@ SIGNATURES = {
     "sr_clip_push_dev": (C.c_int, [_vp, _vp, _vp]),
     "sr_clip_push_u8": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "sr_u8_wait": (C.c_int, [_vp, C.c_int]),
+    "sr_clip_read_est": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "sr_host_alloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
+    "sr_host_free": (C.c_int, [_vp]),
     "sr_fnet": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "sr_srnet": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "sr_profile_enable": (C.c_int, [_vp, C.c_int]),
@@ -137,6 +140,31 @@ def _ptr(a):
 
 def device_count() -> int:
     return lib().sr_device_count()
+
+
+class PinnedArray:
+    """A numpy view of page-locked host memory (sr_host_alloc): what sr_clip_push_u8 copies from / into asynchronously.
+    `.a` is the array, `.ptr` its address; freed on close() / garbage collection (do not keep views of `.a` beyond that)."""
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(int(v) for v in shape), np.dtype(dtype)
+        nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = _vp()
+        _check(lib().sr_host_alloc(C.byref(p), nbytes))
+        self.ptr = p.value
+        self.a = np.frombuffer((C.c_ubyte * nbytes).from_address(self.ptr), dtype=self.dtype).reshape(self.shape)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.a = None
+            lib().sr_host_free(_vp(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:
@@ -250,6 +278,18 @@ class Context:
 
     def u8_wait(self, keep_in_flight=0):
         _check(lib().sr_u8_wait(self._h, int(keep_in_flight)), self._h)
+
+    def clip_read_est(self, first=0, n=1, out=None):
+        """float32 estimates (n,4h,4w,3) of clips first .. first+n-1 as the last clip_push* left them (synchronous).
+        out: a float32 array of that shape to fill (page-locked memory -- PinnedArray.a -- makes the copy several times
+        faster than into pageable memory); default a fresh array."""
+        shape = (int(n), 4 * self.h, 4 * self.w, 3)
+        if out is None:
+            out = np.empty(shape, np.float32)
+        elif out.shape != shape or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError(f"out: expected a contiguous float32 array of shape {shape}")
+        _check(lib().sr_clip_read_est(self._h, int(first), int(n), _ptr(out)), self._h)
+        return out
 
     def fnet(self, lr_t, lr_tm1):
         B = int(np.shape(lr_t)[0])

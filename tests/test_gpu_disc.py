@@ -288,3 +288,50 @@ def test_rejections(sh):
     with pytest.raises(ValueError):
         d.predict(images(1, 2, 32, 32))                        # batch > max_batch
     d.close()
+
+
+# ------------------------------------------------------------------ BASELINE config 5 at its own crop size
+@pytest.fixture(scope="module")
+def config5_case(weights7):
+    """The combined step at config 5's 128x128 LR crops (512x512 HR; BASELINE.json configs[4]), B = 2: the largest size the
+    float64 oracle finishes in about a minute.  One oracle evaluation, shared by the dtypes; no conditioning search (three
+    oracle passes per candidate) -- the 32,768 LR / 524,288 HR pixels per batch average the flip noise that set the toy-size
+    bars (one flipped element of a 4x4 feature map was 7 % of a gradient; the smallest feature map here is 32x32)."""
+    B, h, w = 2, 128, 128
+    dw = rd.make_disc_weights(6, 4 * h, 4 * w)
+    ins, feats, pp = gan_data(5128, B, h, w)
+    want = rd.tecogan_loss_and_grads(weights7, dw, *ins, feats, pp)
+    return (B, h, w), dw, ins, feats, pp, want
+
+
+# No conditioning search here, and the case IS ill conditioned in the discriminator: the float64 oracle's own gradients move
+# by 8.4e-3 (worst tensor, conv2d_40/kernel; median 2.0e-3) when every input moves by +-1e-6, and by 2.1e-3 at +-1e-7 (two
+# images through batch-statistics BatchNormalization: one LeakyReLU flip changes the statistics every element sees); its
+# generator gradients move by 1.7e-4 (median 5.9e-5).  The fp32 kernels (~1e-6 relative arithmetic error over 30 layers) land
+# within a few times that.  Bars = (median over tensors, worst tensor), generator / discriminator, set from what MI355X
+# measured (the print): fp32 generator 1.0e-4 / 5.5e-4, discriminator 3.9e-3 / 2.6e-2; bf16x3 2.7e-4 / 6.6e-4 and 7.2e-3 / 4.3e-2.
+# Arithmetic correctness to 4e-6 is what the conditioned toy sizes above pin; this test pins the size-dependent code paths
+# (wgrad slice plan, lanes, batch statistics over 2 x 256 x 256 maps) and the losses (fp32 1.6e-7, bf16x3 5.5e-6 relative).
+@pytest.mark.parametrize("dtype,tol_g,tol_d,rtol", [("fp32", (3e-4, 2e-3), (1.5e-2, 0.1), 1e-5), ("bf16x3", (1e-3, 3e-3), (2.5e-2, 0.15), 2e-4)])
+def test_config5_crop_size_step_gradients(sh, weights7, config5_case, dtype, tol_g, tol_d, rtol):
+    (B, h, w), dw, ins, feats, pp, (want_l, want_gg, want_dg) = config5_case
+    ctx = sh.Context(h, w, max_batch=B, dtype=dtype, model="tecogan")
+    ctx.load_weights(weights7)
+    d = sh.Discriminator(4 * h, 4 * w, max_batch=B, dtype=dtype)
+    d.load_weights(dw)
+    losses = sh.tecogan_grads(ctx, d, *ins, feats, pp, rd.LOSS_WEIGHTS)
+    import ctypes as C
+    flat = np.empty(ctx.param_count(), np.float32)
+    assert sh.lib().sr_train_read_grads(ctx._h, flat.ctypes.data_as(C.c_void_p)) == 0
+    got_g = ctx.split_grads(flat)
+    got_d = d.split_grads(d.read_grads())
+    ctx.close()
+    d.close()
+    eg = sorted(((rel_err(got_g[k], g), k) for k, g in want_gg.items() if np.abs(g).max() >= 1e-12), reverse=True)
+    ed = sorted(((rel_err(got_d[k], g), k) for k, g in want_dg.items() if np.abs(g).max() >= 1e-12), reverse=True)
+    print(f"\n[config 5 crop, {dtype}] 2 x 128x128 LR: losses max rel dev {np.max(np.abs(np.asarray(losses) - want_l) / np.maximum(np.abs(want_l), 1e-7)):.2e}; "
+          f"generator worst {[(k, '%.2e' % e) for e, k in eg[:2]]} median {np.median([e for e, _ in eg]):.2e}; "
+          f"discriminator worst {[(k, '%.2e' % e) for e, k in ed[:2]]} median {np.median([e for e, _ in ed]):.2e}")
+    assert np.allclose(losses, want_l, rtol=rtol, atol=1e-7), (losses, want_l)
+    check_named(got_g, want_gg, tol_g)
+    check_named(got_d, want_dg, tol_d)

@@ -82,6 +82,49 @@ def test_eval_driver_tiles_state_and_metrics(tmp_path, weights7):
     assert abs(mean_psnr - np.mean(frames_psnr)) < 0.05
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_eval_lock_step_equals_one_clip_at_a_time(tmp_path, weights7, dtype):
+    """stage.eval advances eval.clips_in_flight clips in lock-step through the uint8 output path
+    (sr_clip_push_u8 + page-locked double buffers, float read-back on the metric frames).  Three clips of unequal length
+    (12, 7, 21 frames; 1x2 tiles of 16x24) in one group give, bit for bit, the frames and the metrics of the same clips
+    evaluated one at a time, and of the float path (super_resolve_clip + denormalize)."""
+    import re
+    import utils
+    m = build('frvsr', (16, 24, 3), tmp_path, weights7, rows=1, cols=2, dtype=dtype)
+    os.makedirs(tmp_path / 'clips')
+    lengths = {'a.npy': 12, 'b.npy': 7, 'c.npy': 21}
+    for k, (name, T) in enumerate(lengths.items()):
+        np.save(tmp_path / 'clips' / name, (rn.synth_clip(30 + k, T, 64, 192, scale=4) * 255).astype(np.uint8))
+
+    def run(n_fly, out, **extra):
+        m.configs['eval'] = dict({'output_dir': str(tmp_path / out), 'clips_in_flight': n_fly}, **extra)
+        mean = m.eval()
+        text = open(tmp_path / out / 'metrics.txt').read()
+        rows = sorted(re.sub(r'Inference time:\t\d+', 'Inference time:\tX', l) for l in text.splitlines() if l.startswith('Video:'))
+        return mean, rows, text.splitlines()[-1], {n: np.load(tmp_path / out / n) for n in lengths}
+
+    mean3, rows3, total3, est3 = run(3, 'lock')
+    mean1, rows1, total1, est1 = run(1, 'single')
+    assert len(rows3) == 2 + 1 + 3 and rows3 == rows1 and total3 == total1 and mean3 == mean1
+    # two page-locked slots instead of one per frame (what a group too large for eval.pinned_limit_mb gets)
+    mean_r, rows_r, total_r, est_r = run(3, 'ring', pinned_limit_mb=0)
+    assert rows_r == rows3 and total_r == total3
+    for n in lengths:
+        np.testing.assert_array_equal(est_r[n], est3[n])
+    assert m.eval_fps > 0
+    for n, T in lengths.items():
+        assert est3[n].shape == (T, 64, 192, 3) and est3[n].dtype == np.uint8
+        np.testing.assert_array_equal(est3[n], est1[n])
+    # the float path of the same driver on clip c: same frames after the reference's denormalize, same metric values
+    hr = utils.normalize(np.load(tmp_path / 'clips' / 'c.npy'))
+    import sr_hip
+    lr = sr_hip.blur_cubic_downscale(hr)
+    est_f, stats = m.super_resolve_clip(lr, hr, 'c.npy')
+    np.testing.assert_array_equal(utils.denormalize(est_f), est3['c.npy'])
+    got = [float(re.search(r'PSNR:\t([0-9.]+)', l).group(1)) for l in rows3 if 'c.npy' in l]
+    assert np.allclose(sorted(got), sorted(stats['psnr']), atol=1e-6)
+
+
 def test_train_stage_runs_the_reference_loop(tmp_path, weights7):
     """stage.train through the facade (reference FRVSR.py:76-202): batches of batch_size clips x c_frames
     frames, previous estimates from the generator itself, train_on_batch, checkpoints that load back.  The
