@@ -109,6 +109,27 @@ struct TailArgs {
     int dbg;                       // ablations of the micro-benchmark (SR_TAIL_DBG; 0 in production): 1 no tap sum, 2 no projection, 4 no DMA
 };
 hipError_t launch_tail(TailArgs a, hipStream_t s);
+// FNet's 3x3 convs on split-planar activations (conv_fnet.hip): Cin = 16 npl -> Cout = 32 ncb channels, bf16x3, LeakyReLU(0.2).
+// in [B][npl][H][W][64 B]; out [B][2 ncb][H][W][64 B], or its 2x2 max pooling [B][2 ncb][H/2][W/2][64 B] (pool), or fp32 NHWC
+// [B][H][W][32 ncb] (out_f32).  The launcher fills the mosaic fields.
+struct FConvArgs {
+    const unsigned char* in;
+    unsigned char* out;
+    const unsigned char* wpack;   // [ncb][npl][9 taps][hi, lo][64 lanes] x 16 B (sr_api.hip fconv_entries)
+    const float* bias;            // [32 ncb]
+    unsigned zero_off;            // byte offset from `in` of 64 zero bytes (behind the tensor)
+    unsigned dump_off;            // byte offset from `out` of the 4 KiB tail behind the output tensor
+    int B, H, W;
+    int npl, ncb;
+    int pool, out_f32;
+    int cm, cell_w, cell_h, MW, MH;   // mosaic: images per row, cell pitch, extent (set by the launcher)
+    float inv_cw, inv_ch;
+    int tiles_x, tiles_y;
+};
+hipError_t launch_fnet_conv(FConvArgs a, hipStream_t s);
+size_t fnet_weight_bytes(int cin, int cout);
+hipError_t launch_fnet_input_split(const float* lr_t, const float* lr_tm1, void* out, int B, int H, int W, hipStream_t s);
+hipError_t launch_resize2x_split(const void* in, void* out, int B, int H, int W, int C, hipStream_t s);
 // channel of k index (half h, element e) inside a 16-channel plane of the split-planar layout
 __host__ __device__ constexpr int split_perm(int h, int e) { return e < 4 ? 4 * h + e : 8 + 4 * h + (e - 4); }
 

@@ -177,6 +177,26 @@ std::vector<PackEnt> trunkT_entries(int cin, int cout) {
     return out;
 }
 
+// conv_fnet.hip: [32-channel block of cout][16-channel plane of cin][tap][hi, lo][lane (j, hh)] x 8 bf16, the same fragment as
+// trunk_entries for any (cin, cout)
+std::vector<PackEnt> fconv_entries(int cin, int cout) {
+    std::vector<PackEnt> out;
+    const int ncb = (cout + 31) / 32, npl = (cin + 15) / 16;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int c = 0; c < npl; ++c)
+            for (int t = 0; t < 9; ++t)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int j = lane & 31, hh = lane >> 5, co = 32 * cb + j;
+                    const size_t vbase = ((size_t)((cb * npl + c) * 9 + t) * 2) * 64;
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = 16 * c + split_perm(hh, e);
+                        if (ci < cin && co < cout)
+                            out.push_back({(int32_t)(((size_t)t * cin + ci) * cout + co), (uint32_t)((vbase + lane) * 8 + e)});
+                    }
+                }
+    return out;
+}
+
 // host side of the packing: zero buffer + the listed elements in the arithmetic's storage type
 static std::vector<uint8_t> pack_apply(const std::vector<PackEnt>& ents, size_t bytes, int prec, const float* w) {
     std::vector<uint8_t> out(bytes, 0);
@@ -439,8 +459,82 @@ int check_ready(sr_ctx* c, int B) {
     return SR_OK;
 }
 
+// split-planar FNet (conv_fnet.hip) for this step?  Same rule and the same 32-bit limit as the trunk (use_split): FNet's largest
+// tensor ("u0", 256 B per LR pixel) is a quarter of the trunk's.
+bool use_fnet_split(const sr_ctx* c, int B) {
+    if (c->prec != P_BF16X3 || !c->fnet_split || !c->fnet[0].d_w2) return false;
+    if ((double)c->max_batch * c->h * c->w * 256.0 + 4096.0 > 4294967295.0) return false;
+    return c->fnet_split >= 2 || (size_t)B * c->h * c->w > 65536;
+}
+
+// FNet on conv_fnet.hip: every activation split-planar, MaxPooling2D inside the producing conv, conv2d_13 writes the fp32
+// NHWC tensor conv2d_14's taps-in-N kernel reads.  Buffers are the ones run_fnet uses (same bytes per element).
+static int run_fnet_split(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, float* d_flow) {
+    hipStream_t st = lane_st(c);
+    const int H = c->h, W = c->w;
+    auto b = [&](const char* n) { return (unsigned char*)lane_buf(c, n); };
+    // byte offset of the zero / dump tail (behind image max_batch - 1) from the lane's first image
+    auto tail = [&](const char* n) { return (unsigned)((size_t)(c->max_batch - c->lane_b0) * c->buf_img_bytes[n]); };
+    {
+        ProfScope ps(c, "fnet.input", 0, (double)B * H * W * (24 + 64));
+        LAUNCHCHK(c, "fnet.input", launch_fnet_input_split(d_lr_t, d_lr_tm1, b("x0"), B, H, W, st));
+    }
+    char nm[32];
+    int k = 0;
+    auto conv = [&](const char* in, int h, int w, const char* out, bool pool, bool f32) -> int {
+        const ConvLayer& L = c->fnet[k];
+        snprintf(nm, sizeof nm, "fnet.conv%d", k + 1);
+        ++k;
+        FConvArgs fa = {};
+        fa.in = b(in);
+        fa.out = b(out);
+        fa.wpack = (const unsigned char*)L.d_w2;
+        fa.bias = L.d_bias;
+        fa.zero_off = tail(in);
+        fa.dump_off = tail(out);
+        fa.B = B;
+        fa.H = h;
+        fa.W = w;
+        fa.npl = L.cin_p / 16;
+        fa.ncb = (L.cout + 31) / 32;
+        fa.pool = pool;
+        fa.out_f32 = f32;
+        const double px = (double)B * h * w;
+        ProfScope ps(c, nm, px * 9.0 * L.cin * L.cout * 2.0, px * 4.0 * (L.cin_p + (pool ? L.cout / 4.0 : L.cout)) + (double)fnet_weight_bytes(L.cin, L.cout));
+        LAUNCHCHK(c, nm, launch_fnet_conv(fa, st));
+        return SR_OK;
+    };
+    auto resize = [&](const char* in, int h, int w, int ch, const char* out, int idx) -> int {
+        snprintf(nm, sizeof nm, "fnet.resize%d", idx);
+        ProfScope ps(c, nm, 0, (double)B * h * w * ch * 4 * 5.0);
+        LAUNCHCHK(c, nm, launch_resize2x_split(b(in), b(out), B, h, w, ch, st));
+        return SR_OK;
+    };
+    int rc;
+    // encoder (layers.py:30-36): conv, conv + pool at 32 / 64 / 128 channels, then 256 channels at 1/8 size
+    if ((rc = conv("x0", H, W, "a0", false, false))) return rc;
+    if ((rc = conv("a0", H, W, "p1", true, false))) return rc;
+    if ((rc = conv("p1", H / 2, W / 2, "a1", false, false))) return rc;
+    if ((rc = conv("a1", H / 2, W / 2, "p2", true, false))) return rc;
+    if ((rc = conv("p2", H / 4, W / 4, "a2", false, false))) return rc;
+    if ((rc = conv("a2", H / 4, W / 4, "p3", true, false))) return rc;
+    if ((rc = conv("p3", H / 8, W / 8, "a3", false, false))) return rc;
+    if ((rc = conv("a3", H / 8, W / 8, "b3", false, false))) return rc;
+    // decoder (layers.py:37-43)
+    if ((rc = resize("b3", H / 8, W / 8, 256, "u2", 1))) return rc;
+    if ((rc = conv("u2", H / 4, W / 4, "a2", false, false))) return rc;
+    if ((rc = conv("a2", H / 4, W / 4, "b2", false, false))) return rc;
+    if ((rc = resize("b2", H / 4, W / 4, 128, "u1", 2))) return rc;
+    if ((rc = conv("u1", H / 2, W / 2, "a1", false, false))) return rc;
+    if ((rc = conv("a1", H / 2, W / 2, "b1", false, false))) return rc;
+    if ((rc = resize("b1", H / 2, W / 2, 64, "u0", 3))) return rc;
+    if ((rc = conv("u0", H, W, "a0", false, true))) return rc;          // conv2d_13: fp32 NHWC for the taps-in-N kernel
+    return run_conv(c, c->prec, st, c->fnet[13], B, {b("a0"), H, W, d_flow, 2, 2, 1, nullptr, 0, A_TANH}, "fnet.conv14");
+}
+
 // FNet: reference layers.py:27-45
 int run_fnet(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, float* d_flow) {
+    if (c->step_fnet_split) return run_fnet_split(c, B, d_lr_t, d_lr_tm1, d_flow);
     const int bf = c->prec == P_BF16, P = c->prec;
     const int af = bf ? 0 : 1;   // activations are float?
     hipStream_t st = lane_st(c);
@@ -690,6 +784,7 @@ int run_step(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, const
     const bool tiny = (size_t)B * c->h * c->w <= 65536;
     const int lanes = tiny ? 1 : std::min(c->dual + 1, B);
     c->step_split = use_split(c, B);
+    c->step_fnet_split = use_fnet_split(c, B);
     if (lanes < 2 || c->prof_on)
         return run_step_lane(c, B, d_lr_t, d_lr_tm1, d_est_prev, d_est_out, d_lr_warp, d_hr_warp, warp_only);
     const size_t lr = (size_t)c->h * c->w * 3, hr = lr * 16;
@@ -823,6 +918,7 @@ static int create_common(sr_ctx** out, int device, int h_in, int w_in, int ch, i
     c->trunk_up1 = getenv("SR_NO_TRUNK_UP1") ? 0 : 1;
     if (const char* e = getenv("SR_TAIL")) c->tail_kernel = atoi(e);
     if (const char* e = getenv("SR_SPLIT_TRUNK")) c->split_trunk = atoi(e);
+    if (const char* e = getenv("SR_FNET")) c->fnet_split = atoi(e);
     int rc = SR_OK;
     auto bail = [&](int code) {
         g_err = c->err;
@@ -989,6 +1085,14 @@ int sr_commit_weights(sr_ctx* c) {
             L.ents2 = i < 21 ? trunk_entries(L.cin, L.cout) : (tk ? trunkT_entries(L.cin, L.cout) : pack_entries(L, c->prec, PK_FWD, true));
             const size_t bytes = tk ? trunk_weight_bytes() : (size_t)L.ncb * L.wstride_cb * 16;
             int rc = upload_alt(c, L, bytes, c->tensors[28 + 2 * i].data.data());
+            if (rc) return rc;
+        }
+    }
+    if (c->prec == P_BF16X3 && c->fnet_split) {   // conv_fnet.hip: second packing of FNet's 13 MFMA convs (conv2d_14 stays on the taps-in-N kernel)
+        for (int i = 0; i < 13; ++i) {
+            ConvLayer& L = c->fnet[i];
+            L.ents2 = fconv_entries(L.cin, L.cout);
+            int rc = upload_alt(c, L, fnet_weight_bytes(L.cin, L.cout), c->tensors[2 * i].data.data());
             if (rc) return rc;
         }
     }
@@ -1198,6 +1302,7 @@ int sr_fnet(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, float* flo
     c->clip_active = false;
     hipStream_t st = c->stream;
     if ((rc = put_in(c, c->d_lr_t, lr_t, false, B, 1, 3)) || (rc = put_in(c, c->d_lr_tm1, lr_tm1, false, B, 1, 3))) return rc;
+    c->step_fnet_split = use_fnet_split(c, B);
     rc = run_fnet(c, B, c->d_lr_t, c->d_lr_tm1, c->d_flow);
     if (rc) return rc;
     if ((rc = get_out(c, flow, false, c->d_flow, B, 1, 2))) return rc;

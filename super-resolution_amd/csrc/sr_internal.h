@@ -106,6 +106,10 @@ struct sr_ctx {
     int fuse_gather = 1;                 // SRNet tail: conv2d_36's tap sum inside conv2d_transpose_2's kernel (SR_NO_FUSE_GATHER=1: tap_gather_kernel)
     int fuse_pool = 1;                   // FNet: MaxPooling2D in the producing conv's epilogue (SR_NO_FUSE_POOL=1: separate kernel)
     bool step_split = false;   // the step being enqueued uses it
+    // bf16x3 only: FNet on conv_fnet.hip with split-planar activations: 1 = steps of more than 65,536 pixels, 2 = always
+    // (SR_FNET=2, tests), 0 = never (SR_FNET=0: conv_mfma.hip)
+    int fnet_split = 1;
+    bool step_fnet_split = false;
     // two lanes: a step's batch is split into halves that run on `stream` and on `stream2` between a
     // fork and a join event, so one half's kernels fill the partial last round of workgroups (and the
     // under-filled low-resolution FNet launches) of the other.  SR_NO_DUAL=1 disables.
@@ -144,6 +148,7 @@ void plan_layer(ConvLayer& L, int prec, int mode, int cin, int cout);
 std::vector<PackEnt> pack_entries(const ConvLayer& L, int prec, int kind, bool kperm = false);
 std::vector<PackEnt> trunk_entries(int cin, int cout);
 std::vector<PackEnt> trunkT_entries(int cin, int cout);
+std::vector<PackEnt> fconv_entries(int cin, int cout);
 int upload_alt(sr_ctx* c, ConvLayer& L, size_t bytes, const float* w);   // L.ents2 -> L.d_w2 (bf16x3)
 std::vector<PackEnt> proj_entries(int prec, int cout);
 size_t proj_bytes(int prec);

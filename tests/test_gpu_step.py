@@ -131,6 +131,36 @@ def test_fused_max_pooling_is_the_pooling_kernel(sh, weights7, B, h, w, dtype):
         assert np.abs(flows[0] - want).max() <= FP32_TOL
 
 
+@pytest.mark.parametrize("B,h,w", [(1, 8, 8), (3, 16, 40), (2, 24, 72), (2, 72, 24), (1, 8, 136), (5, 40, 64), (7, 24, 40), (2, 184, 320)])
+def test_split_planar_fnet(sh, weights7, B, h, w):
+    """FNet on conv_fnet.hip (bf16x3; SR_FNET=2 forces it for shapes below the production threshold): split-planar activations,
+    weights streamed with the planes, the batch tiled as a mosaic (images side by side with zero gutters -- 1 to 7 images of sizes
+    that leave tiles half empty, cut images, several mosaic rows), MaxPooling2D inside the producing conv.  Flow against the
+    oracle at the same bar as the generic kernels (1e-4), and against the generic path itself; a smaller batch on the same
+    ctx; determinism."""
+    lr_t = np.stack([rn.synth_clip(40 + i, 1, h, w)[0] for i in range(B)])
+    lr_tm1 = np.stack([rn.synth_clip(60 + i, 1, h, w)[0] for i in range(B)])
+    want = rt.to_nhwc(rt.fnet(rt.TorchWeights(weights7), rt.to_nchw(lr_t), rt.to_nchw(lr_tm1)))
+    flows = {}
+    for mode in ("2", "0"):
+        os.environ["SR_FNET"] = mode
+        try:
+            ctx = sh.Context(h, w, max_batch=B, dtype="bf16x3")
+            ctx.load_weights(weights7)
+            flows[mode] = ctx.fnet(lr_t, lr_tm1)
+            if mode == "2":
+                again = ctx.fnet(lr_t, lr_tm1)
+                first = ctx.fnet(lr_t[:1], lr_tm1[:1]) if B > 1 else None
+            ctx.close()
+        finally:
+            os.environ.pop("SR_FNET", None)
+    assert np.abs(flows["2"] - want).max() <= 1e-4
+    assert np.abs(flows["2"] - flows["0"]).max() <= 1e-4
+    assert np.array_equal(again, flows["2"])
+    if first is not None:
+        assert np.abs(first[0] - want[0]).max() <= 1e-4
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16x3", "bf16"])
 @pytest.mark.parametrize("B,h,w", [(2, 24, 40), (1, 8, 72), (3, 16, 8), (1, 96, 144), (1, 8, 8), (1, 8, 16)])
 def test_in_kernel_tap_gather_is_the_gather_kernel(sh, weights7, B, h, w, dtype):
