@@ -288,8 +288,8 @@ int sr_disc_apply(sr_disc* d, const float* d_grads, float grad_scale, float lr, 
                   int slot, int reset_moments);
 /* tecogan.train_on_batch (reference TecoGAN.py:87-108,122-131,469-479) up to the optimizer, ctx model SR_TECOGAN:
  * inputs [lr_t, lr_tm1, est_tm1, next_est (I_hr_fut), next_hat_est (I_hr_warp_fut), bic_past, bic_pres, bic_fut], targets
- * [hr_t, ones, d_1..d_4 (d_targets: 4 host pointers), hr_t x 4 (VGG19 terms: ImageNet weights are a download, the terms
- * count as 0), pp_target (the batch-flipped hr_t), lr_t]; loss_weights: the 12 of TecoGAN.py:127-130 (the warp weight must
+ * [hr_t, ones, d_1..d_4 (d_targets: 4 host pointers), hr_t x 4 (VGG19 terms: evaluated when sr_tecogan_set_vgg attached the
+ * weights, else 0 -- ImageNet weights are a download), pp_target (the batch-flipped hr_t), lr_t]; loss_weights: the 12 of TecoGAN.py:127-130 (the warp weight must
  * be 1); losses[13] = total + the 12 unweighted parts in Keras' order.  BatchNormalization runs in training mode (learning
  * phase 1) without touching the moving statistics.  Generator gradient -> the ctx (sr_train_read_grads), discriminator
  * gradient -> the discriminator (sr_disc_read_grads); sr_tecogan_read_grads_dev copies both to DEVICE buffers (NULL skips
@@ -315,6 +315,27 @@ int sr_tecogan_read_grads_dev(sr_ctx* ctx, sr_disc* d, float* d_gen_out, float* 
  * the two discriminator losses.  Same arithmetic as the step-by-step entry points (tests/test_gpu_disc.py). */
 int sr_tecogan_iteration(sr_ctx* ctx, sr_disc* d, int B, const float* const* arrays, const float* loss_weights, float lr,
                          float beta1, float beta2, float eps, int64_t t0, int train_disc, float* losses, float* disc_losses);
+
+/* TecoGAN's VGG19 perceptual terms (reference TecoGAN.py:125,129,867-901: vgg_22 / vgg_34 / vgg_44 / vgg_54 =
+ * K.mean(K.square(f(y_true) - f(y_pred))) with f = keras.applications.VGG19(include_top=False) up to block2_conv2 /
+ * block3_conv4 / block4_conv4 / block5_conv4, ReLU included, images fed as they are).  The reference downloads the ImageNet
+ * weights; here the caller supplies the 32 tensors (index 2 l = kernel (3,3,Cin,Cout) HWIO, 2 l + 1 = bias of conv l in
+ * Keras order block1_conv1 .. block5_conv4) -- without them the combined step reports the four terms as 0.  H, W: the HR
+ * size, multiples of 16; dtype SR_FP32 or SR_BF16X3.  sr_vgg_loss_grads: host images (B,H,W,3) in, losses4 = the four
+ * unweighted terms, grad_pred (nullable, (B,H,W,3)) = gradient of sum weights4[k] * loss_k with respect to y_pred (nothing
+ * of VGG19 is trainable, TecoGAN.py:869-873).  sr_tecogan_set_vgg attaches the object to a SR_TECOGAN ctx (NULL detaches):
+ * sr_tecogan_grads / sr_tecogan_iteration then evaluate outputs 6..9 on (hr_t, I_est_t) with loss_weights[6..9] and add
+ * their gradient to the generator's.  The ctx does not own the object: detach before sr_vgg_destroy. */
+typedef struct sr_vgg sr_vgg;
+const char* sr_vgg_last_error(const sr_vgg* v);
+int sr_vgg_tensor_count(void);
+int sr_vgg_create(sr_vgg** out, int device, int H, int W, int max_batch, int dtype);
+int sr_vgg_destroy(sr_vgg* v);
+int sr_vgg_set_tensor(sr_vgg* v, int index, const float* host, const int64_t* shape, int rank);
+int sr_vgg_commit(sr_vgg* v);
+int sr_vgg_loss_grads(sr_vgg* v, int B, const float* y_true, const float* y_pred, const float* weights4, float* losses4,
+                      float* grad_pred);
+int sr_tecogan_set_vgg(sr_ctx* ctx, sr_vgg* v);
 
 /* The ONE entry point that allocates nothing.  It has no counterpart in the reference; it exists for callers
  * that cannot call hipMalloc: code under HIP graph capture, tight training loops, harnesses that forbid

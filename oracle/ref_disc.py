@@ -160,8 +160,9 @@ def disc_loss_and_grads(weights, imgs, labels):
 
 
 def tecogan_loss_and_grads(gen_weights, disc_weights, lr_t, lr_tm1, est_tm1, next_est, next_hat_est, bic_past, bic_pres,
-                           bic_fut, hr_t, d_targets, pp_target, loss_weights=None, dtype=torch.float64):
-    """tecogan.train_on_batch up to the optimizer (TecoGAN.py:87-108,122-131,469-479), VGG weights taken as 0.
+                           bic_fut, hr_t, d_targets, pp_target, loss_weights=None, dtype=torch.float64, vgg_weights=None):
+    """tecogan.train_on_batch up to the optimizer (TecoGAN.py:87-108,122-131,469-479).  vgg_weights: the 32 VGG19 tensors
+    (oracle/ref_vgg.py) for the four perceptual terms (TecoGAN.py:125,129); None = those terms 0 (no ImageNet weights).
     Inputs NHWC numpy.  The discriminator sees [est_tm1, est, next_est, hr_warp(est_tm1), est, next_hat_est, bic_past,
     bic_pres, bic_fut] with BatchNorm in training mode (Keras learning phase 1 inside train_on_batch).
     Returns (losses [total, gt, dst, ds1..ds4, 0, 0, 0, 0, pingpong, warp] -- unweighted parts like Keras reports them --,
@@ -180,8 +181,12 @@ def tecogan_loss_and_grads(gen_weights, disc_weights, lr_t, lr_tm1, est_tm1, nex
     mse = lambda a, b: ((a - b) ** 2).mean()
     parts = [mse(est, n(hr_t)), keras_bce(p, torch.ones_like(p))]
     parts += [mse(f, n(t)) for f, t in zip(feats, d_targets)]
-    zero = torch.zeros((), dtype=dtype)
-    parts += [zero, zero, zero, zero]                       # VGG 22 / 34 / 44 / 54: weights unavailable offline
+    if vgg_weights is not None:                             # outputs 6..9 are I_est_t, targets hr_t (TecoGAN.py:107,474-478)
+        from . import ref_vgg
+        parts += ref_vgg.vgg_losses_t(ref_vgg.to_t(vgg_weights, dtype), n(hr_t), est)
+    else:
+        zero = torch.zeros((), dtype=dtype)
+        parts += [zero, zero, zero, zero]                   # VGG 22 / 34 / 44 / 54: weights unavailable offline
     parts += [mse(est, n(pp_target)), mse(lr_warp, x[0])]
     total = sum(w * q for w, q in zip(lw, parts))
     gl, gnames = [], []

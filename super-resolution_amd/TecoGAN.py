@@ -8,9 +8,11 @@ generator pre-training (TecoGAN.py:164-275: two MSE losses, learning rate halved
 to 2.5e-5) and the adversarial phase (TecoGAN.py:277-527: ping-pong batch, two discriminator steps, two
 combined steps per iteration), every step on the native library.
 
-Not built: the four VGG19 perceptual terms (TecoGAN.py:125,129,867-901).  They need the ImageNet weights
-that ``keras.applications.VGG19`` downloads; there is no network here, so their loss weights count as 0 and
-the step reports them as 0 (the other eight terms are exact).
+The four VGG19 perceptual terms (TecoGAN.py:125,129,867-901) need the ImageNet weights that ``keras.applications.VGG19``
+downloads; there is no network here, so they come from a file: ``train.vgg19_weights: path`` (.npz / .h5 with the 32
+tensors of ``VGG19(include_top=False)`` in Keras order, e.g. written once by ``model.save_weights`` on a machine that has
+them).  With the file the combined step evaluates all twelve terms (native VGG19 forward / input gradient, sr_vgg_*);
+without it those four count as 0 and are reported as 0 (the other eight terms are exact either way).
 """
 import os
 
@@ -45,17 +47,43 @@ class TecoGAN(FrameRecurrentVideoSR):
         self.generator.compile(loss=['mean_squared_error', 'mean_squared_error'], loss_weights=[1., 1.], optimizer=self.opt)
         self.discriminator.compile(loss=['binary_crossentropy'] + ['mean_squared_error'] * 4,
                                    loss_weights=[1., 0., 0., 0., 0.], optimizer=self.opt)
+        vgg_path = train_cfg.get('vgg19_weights')
+        if vgg_path:
+            import weights_io
+            path = vgg_path if os.path.isabs(vgg_path) else os.path.join(self.configs.get('root_dir', './'), vgg_path)
+            print('[INFO] Loading VGG19 weights for the perceptual losses ...')
+            self.tecogan.set_vgg_weights([a for _, a in weights_io.read_tensors(path)])
         self.tecogan.compile(loss=['mean_squared_error', 'binary_crossentropy'] + ['mean_squared_error'] * 4
                              + [self.vgg_22, self.vgg_34, self.vgg_44, self.vgg_54] + ['mean_squared_error'] * 2,
                              loss_weights=list(TECOGAN_LOSS_WEIGHTS), optimizer=self.opt)
         del self.frvsr
         print('[INFO] Temporally Coherent GAN ready.')
 
-    # the reference's perceptual losses (TecoGAN.py:867-901): placeholders that say why they are not evaluated
-    def _vgg(self, *_):
-        raise NotImplementedError('VGG19 perceptual losses need ImageNet weights (a download); their loss weights count as 0')
+    # the reference's perceptual losses (TecoGAN.py:867-901) as stand-alone functions of two HR batches (the combined step
+    # evaluates them on the device together with their gradient; these are for inspection and tests)
+    def _vgg(self, k, y_true, y_pred):
+        if getattr(getattr(self, 'tecogan', None), 'vgg_weights', None) is None:
+            raise NotImplementedError('VGG19 perceptual losses need the ImageNet weights (a download): give them as '
+                                      'train.vgg19_weights (32 tensors in Keras order); without them the terms count as 0')
+        y_true = np.asarray(y_true, np.float32)
+        v = sr_hip.Vgg19(self.hr_shape[0], self.hr_shape[1], max_batch=len(y_true), dtype=self.core.dtype, device=self.core.device)
+        try:
+            v.load_weights(self.tecogan.vgg_weights)
+            return v.loss_grads(y_true, y_pred, want_grad=False)[0][k]
+        finally:
+            v.close()
 
-    vgg_22 = vgg_34 = vgg_44 = vgg_54 = _vgg
+    def vgg_22(self, y_true, y_pred):
+        return self._vgg(0, y_true, y_pred)
+
+    def vgg_34(self, y_true, y_pred):
+        return self._vgg(1, y_true, y_pred)
+
+    def vgg_44(self, y_true, y_pred):
+        return self._vgg(2, y_true, y_pred)
+
+    def vgg_54(self, y_true, y_pred):
+        return self._vgg(3, y_true, y_pred)
 
     def _generator(self):
         return self.generator
@@ -116,6 +144,7 @@ class TecoGAN(FrameRecurrentVideoSR):
             # (sr_tecogan_iteration; the calls below are the same pass through the Keras-shaped model objects)
             opt = self.opt
             ctx, d = self.core.ctx(k), self.discriminator.native(k)
+            self.tecogan.attach_vgg(ctx, k)
             loss, _ = sr_hip.tecogan_iteration(ctx, d, b, self.tecogan.loss_weights, opt.iterations, lr=opt.lr, beta_1=opt.beta_1,
                                                beta_2=opt.beta_2, epsilon=opt.epsilon, train_disc=self.tecogan.train_discriminator)
             opt.iterations += 4

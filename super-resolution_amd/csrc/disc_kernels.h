@@ -37,7 +37,10 @@ hipError_t launch_gather_w4(const float* dw3, float* dw4, int C, int O, hipStrea
 
 size_t teco_est_grad_workspace_bytes(long npix);
 hipError_t launch_teco_est_grad(const float* est, const float* hr, const float* pp, const float* g27, const float* s_out, float* g_out,
-                                double* partial, float* loss_gt, float* loss_pp, long npix, float w_gt, float w_pp, hipStream_t s);
+                                double* partial, float* loss_gt, float* loss_pp, long npix, float w_gt, float w_pp, hipStream_t s,
+                                const float* gvgg = nullptr);   // gvgg [npix,3] (nullable): gradient of the VGG19 terms w.r.t. est
+hipError_t launch_feat_mse_grad(const float* ft, const float* fp, float* g, double* partial, float* loss_out, long n, float weight,
+                                int accumulate, hipStream_t s);
 hipError_t launch_add_hat_s2d(const float* g27, float* g_sin, int B, int H, int W, int gcs, hipStream_t s);
 
 }  // namespace sr

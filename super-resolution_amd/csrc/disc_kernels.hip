@@ -406,6 +406,39 @@ hipError_t launch_sqdiff_grad(const float* a, const float* t, float* g, double* 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ VGG19 feature terms (sr_vgg.hip)
+// loss = mean (fp - ft)^2 over n elements of two post-ReLU feature maps; g (+)= gscale * (fp - ft) where fp > 0 (the gradient
+// with respect to the tapped conv's PRE-activation: ReLU is inside the Keras layer, reference TecoGAN.py:872)
+__global__ __launch_bounds__(256) void feat_mse_grad_kernel(const float* __restrict__ ft, const float* __restrict__ fp, float* __restrict__ g,
+                                                            double* __restrict__ partial, long n, float gscale, int accumulate) {
+    __shared__ double red[256];
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    double sq = 0.0;
+    if (i < n) {
+        const float y = fp[i];
+        const float d = y - ft[i];
+        sq = (double)d * d;
+        if (g) g[i] = (accumulate ? g[i] : 0.f) + (y > 0.f ? gscale * d : 0.f);
+    }
+    red[threadIdx.x] = sq;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+hipError_t launch_feat_mse_grad(const float* ft, const float* fp, float* g, double* partial, float* loss_out, long n, float weight,
+                                int accumulate, hipStream_t s) {
+    const int nb = blocks_for(n, 256);
+    hipLaunchKernelGGL(feat_mse_grad_kernel, dim3(nb), dim3(256), 0, s, ft, fp, g, partial, n, (float)(2.0 * (double)weight / (double)n), accumulate);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sum_partials2_kernel, dim3(1), dim3(256), 0, s, partial, nb, 1.0 / (double)n, loss_out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ the 4x4 kernel's gradient out of the 3x3 one's
 // dW[ky,kx,c,o] = dW3[dy+1, dx+1, (py*2+px)*C + c, o] with ky = 2 dy + py + 1 (sr_disc.hip: conv4x4 s2 = conv3x3 on space_to_depth)
 __global__ void gather_w4_kernel(const float* __restrict__ dw3, float* __restrict__ dw4, int C, int O) {
@@ -436,7 +469,8 @@ hipError_t launch_gather_w4(const float* dw3, float* dw4, int C, int O, hipStrea
 __global__ __launch_bounds__(256) void teco_est_grad_kernel(const float* __restrict__ est, const float* __restrict__ hr,
                                                             const float* __restrict__ pp, const float* __restrict__ g27,
                                                             const float* __restrict__ s_out, float* __restrict__ g_out,
-                                                            double* __restrict__ partial, long npix, float sc_gt, float sc_pp) {
+                                                            double* __restrict__ partial, long npix, float sc_gt, float sc_pp,
+                                                            const float* __restrict__ gvgg) {
     __shared__ double red[2][256];
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     double q0 = 0.0, q1 = 0.0;
@@ -451,6 +485,7 @@ __global__ __launch_bounds__(256) void teco_est_grad_kernel(const float* __restr
             q1 = (double)d1 * d1;
             gv = sc_gt * d0 + sc_pp * d1;
             if (g27) gv += g27[p * 32 + 3 + c] + g27[p * 32 + 12 + c];
+            if (gvgg) gv += gvgg[p * 3 + c];                         // the four VGG19 feature terms (sr_vgg.hip), already weighted
             gv *= 1.f - a * a;                                       // tanh
             const float u = s_out[p * 3 + c];
             if (!(u > 0.f && u < 1.f)) gv = 0.f;                     // ReLU(max_value = 1) of SRNet's last layer
@@ -476,11 +511,12 @@ __global__ __launch_bounds__(256) void teco_est_grad_kernel(const float* __restr
 size_t teco_est_grad_workspace_bytes(long npix) { return (size_t)2 * blocks_for(npix * 4, 256) * sizeof(double); }
 
 hipError_t launch_teco_est_grad(const float* est, const float* hr, const float* pp, const float* g27, const float* s_out, float* g_out,
-                                double* partial, float* loss_gt, float* loss_pp, long npix, float w_gt, float w_pp, hipStream_t s) {
+                                double* partial, float* loss_gt, float* loss_pp, long npix, float w_gt, float w_pp, hipStream_t s,
+                                const float* gvgg) {
     const int nb = blocks_for(npix * 4, 256);
     const double cnt = (double)npix * 3.0;
     hipLaunchKernelGGL(teco_est_grad_kernel, dim3(nb), dim3(256), 0, s, est, hr, pp, g27, s_out, g_out, partial, npix,
-                       (float)(2.0 * w_gt / cnt), (float)(2.0 * w_pp / cnt));
+                       (float)(2.0 * w_gt / cnt), (float)(2.0 * w_pp / cnt), gvgg);
     hipLaunchKernelGGL(sum_partials2_kernel, dim3(1), dim3(256), 0, s, partial, nb, 1.0 / cnt, loss_gt);
     hipLaunchKernelGGL(sum_partials2_kernel, dim3(1), dim3(256), 0, s, partial + nb, nb, 1.0 / cnt, loss_pp);
     return hipGetLastError();

@@ -11,6 +11,7 @@
 #include <vector>
 
 struct sr_train_state;   // sr_train.hip
+struct sr_vgg;           // sr_vgg.h
 
 namespace srh {
 
@@ -125,6 +126,7 @@ struct sr_ctx {
     std::vector<hipEvent_t> ev_pool;
     // training (sr_train.hip); the host copies in `tensors` are stale while train->host_stale
     sr_train_state* train = nullptr;
+    sr_vgg* vgg = nullptr;   // VGG19 feature terms of the combined step (sr_tecogan_set_vgg); not owned
 };
 
 namespace srh {

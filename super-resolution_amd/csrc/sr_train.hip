@@ -10,6 +10,7 @@
 //   weight gradients, transposed-conv data gradient, gathers: train_kernels.hip
 #include "sr_internal.h"
 #include "sr_disc.h"
+#include "sr_vgg.h"
 
 #include <cmath>
 #include <cstdio>
@@ -893,21 +894,37 @@ static int tecogan_grads_core(sr_ctx* c, sr_disc* d, int B, const float* d_lr_t,
     // generator backward from the weighted losses on its output + what came back through the discriminator
     const long npix = (long)B * 16 * H * W;
     // (the discriminator's reduction workspace is sized for its 64-channel HR tensor: 16x what this needs)
+    // the four VGG19 terms on (hr_t, I_est_t) (TecoGAN.py:107,125,129) when their weights are attached: losses + the gradient
+    // w.r.t. the estimate, added below before tanh' and the clip mask
+    const float* gvgg = nullptr;
+    if (c->vgg) {
+        sr_vgg* v = c->vgg;
+        if (!v->committed || v->device != c->device || v->H != 4 * H || v->W != 4 * W || B > v->max_batch)
+            return fail(c, SR_ERR_ARG, "the attached VGG19 object (%dx%d, max batch %d, device %d, committed %d) does not fit this step", v->H,
+                        v->W, v->max_batch, v->device, (int)v->committed);
+        hipStream_t old = v->stream;
+        v->stream = st;
+        rc = vgg_loss_grads_dev(v, B, d_hr, est, lw + 6, v->g3);
+        v->stream = old;
+        if (rc) return fail(c, rc, "%s", v->err.c_str());
+        gvgg = v->g3;
+    }
     LAUNCHCHK(c, "teco_est_grad", launch_teco_est_grad(est, d_hr, d_pp, d->gS, t.a("s_out"), t.a("g_est"), d->red,
-                                                       d->d_loss + 5, d->d_loss + 6, npix, lw[0], lw[10], st));
+                                                       d->d_loss + 5, d->d_loss + 6, npix, lw[0], lw[10], st, gvgg));
     t.ext_g_est = true;
     t.g27 = d->gS;
     if ((rc = train_backward(t, d_lr_t, d_lr_tm1, d_est_tm1, d_hr, est, c->d_lr_warp, c->d_flow))) return rc;
-    float dl[8] = {0}, gl[2] = {0};
+    float dl[8] = {0}, gl[2] = {0}, vl[4] = {0};
+    if (c->vgg) HIPCHK(c, hipMemcpyAsync(vl, c->vgg->d_loss, sizeof vl, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(dl, d->d_loss, sizeof dl, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(gl, T->d_loss, sizeof gl, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     if (losses) {   // Keras order: total, then the twelve outputs' unweighted losses (TecoGAN.py:105-108)
-        const float parts[12] = {dl[5], dl[0], dl[1], dl[2], dl[3], dl[4], 0.f, 0.f, 0.f, 0.f, dl[6], gl[1]};
+        const float parts[12] = {dl[5], dl[0], dl[1], dl[2], dl[3], dl[4], vl[0], vl[1], vl[2], vl[3], dl[6], gl[1]};
         double total = 0.0;
         for (int i = 0; i < 12; ++i) {
             losses[1 + i] = parts[i];
-            if (i < 6 || i > 9) total += (double)lw[i] * parts[i];
+            if (i < 6 || i > 9 || c->vgg) total += (double)lw[i] * parts[i];
         }
         losses[0] = (float)total;
     }
@@ -921,6 +938,19 @@ struct DiscStreamSwap {
     DiscStreamSwap(sr_disc* d_, hipStream_t st) : d(d_), old(d_->stream) { d->stream = st; }
     ~DiscStreamSwap() { d->stream = old; }
 };
+
+int sr_tecogan_set_vgg(sr_ctx* c, sr_vgg* v) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    if (v) {
+        if (c->model != SR_TECOGAN) return fail(c, SR_ERR_STATE, "the VGG19 terms belong to the combined step of a ctx created with model SR_TECOGAN");
+        if (!v->committed) return fail(c, SR_ERR_WEIGHTS, "VGG19 weights not committed (sr_vgg_set_tensor x32 + sr_vgg_commit)");
+        if (v->device != c->device || v->H != 4 * c->h || v->W != 4 * c->w)
+            return fail(c, SR_ERR_ARG, "VGG19 object for %dx%d on device %d does not fit this generator (%dx%d HR, device %d)", v->H, v->W, v->device,
+                        4 * c->h, 4 * c->w, c->device);
+    }
+    c->vgg = v;
+    return SR_OK;
+}
 
 int sr_tecogan_grads(sr_ctx* c, sr_disc* d, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1,
                      const float* next_est, const float* next_hat_est, const float* bic_past, const float* bic_pres,

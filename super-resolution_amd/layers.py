@@ -601,6 +601,37 @@ class TecoGANModel(_Model):
         self.optimizer = None
         self.loss_weights = list(TECOGAN_LOSS_WEIGHTS)
         self._gbuf = None
+        self.vgg_weights = None      # the 32 VGG19 tensors of the perceptual terms, or None (terms count as 0)
+        self._vgg = None
+
+    def set_vgg_weights(self, tensors):
+        """The 32 arrays of keras.applications.VGG19(include_top=False) in Keras order (block1_conv1 kernel, bias, ...), or
+        None: with them the combined step evaluates outputs 6..9 (reference TecoGAN.py:125,129), without them they count as 0."""
+        if tensors is not None:
+            tensors = [np.ascontiguousarray(a, np.float32) for a in tensors]
+            if len(tensors) != 32:
+                raise ValueError(f'VGG19 (include_top=False) has 32 weight tensors, got {len(tensors)}')
+        if self._vgg is not None:
+            self._vgg.close()
+            self._vgg = None
+        self.vgg_weights = tensors
+
+    def attach_vgg(self, ctx, batch):
+        """Make `ctx` evaluate the VGG19 terms (or not) according to vgg_weights; the native object is sized by the largest batch seen."""
+        if self.vgg_weights is None:
+            if getattr(ctx, '_vgg', None) is not None:
+                ctx.set_vgg(None)
+            return
+        if self._vgg is None or batch > self._vgg.max_batch:
+            if self._vgg is not None:
+                if getattr(ctx, '_vgg', None) is self._vgg:
+                    ctx.set_vgg(None)
+                self._vgg.close()
+            H, W, _ = self.gen.core.hr_shape
+            self._vgg = sr_hip.Vgg19(H, W, max_batch=int(batch), dtype=self.gen.core.dtype, device=self.gen.core.device)
+            self._vgg.load_weights(self.vgg_weights)
+        if getattr(ctx, '_vgg', None) is not self._vgg:
+            ctx.set_vgg(self._vgg)
 
     def named_weights(self):
         return self.gen.named_weights() + self.disc.named_weights()
@@ -619,8 +650,9 @@ class TecoGANModel(_Model):
         self.optimizer = optimizer if optimizer is not None else Adam()
 
     def train_on_batch(self, x, y):
-        """-> [total, GT, Dst, Ds1..Ds4, 0, 0, 0, 0, ping-pong, warp] (Keras order).  Targets: y[1] must be ones, y[11] must be
-        I_LR_t (reference TecoGAN.py:473-476); y[6..9] (VGG targets) are ignored."""
+        """-> [total, GT, Dst, Ds1..Ds4, VGG22, VGG34, VGG44, VGG54 (0 without vgg_weights), ping-pong, warp] (Keras order).
+        Targets: y[1] must be ones, y[11] must be I_LR_t (reference TecoGAN.py:473-476); y[6..9] are y[0] in the reference
+        (TecoGAN.py:474-478) and the native step uses y[0] for them."""
         if self.optimizer is None:
             raise RuntimeError('You must compile a model before training/testing. Use `model.compile(optimizer, loss)`.')
         lr_t, lr_tm1, est_tm1, next_est, next_hat_est, bic_past, bic_pres, bic_fut = _as_list(x)
@@ -634,6 +666,7 @@ class TecoGANModel(_Model):
         B = len(lr_t)
         ctx = self.gen.core.ctx(B)
         d = self.disc.native(B)
+        self.attach_vgg(ctx, B)
         opt = self.optimizer
         losses = sr_hip.tecogan_grads(ctx, d, lr_t, lr_tm1, est_tm1, next_est, next_hat_est, bic_past, bic_pres, bic_fut, y[0], y[2:6],
                                       y[10], self.loss_weights)

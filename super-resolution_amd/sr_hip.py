@@ -92,6 +92,14 @@ SIGNATURES = {
     "sr_tecogan_read_grads_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
     "sr_tecogan_iteration": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp), _f32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64,
                                        C.c_int, _f32p, _f32p]),
+    "sr_vgg_last_error": (C.c_char_p, [_vp]),
+    "sr_vgg_tensor_count": (C.c_int, []),
+    "sr_vgg_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sr_vgg_destroy": (C.c_int, [_vp]),
+    "sr_vgg_set_tensor": (C.c_int, [_vp, C.c_int, _vp, _i64p, C.c_int]),
+    "sr_vgg_commit": (C.c_int, [_vp]),
+    "sr_vgg_loss_grads": (C.c_int, [_vp, C.c_int, _vp, _vp, _f32p, _f32p, _vp]),
+    "sr_tecogan_set_vgg": (C.c_int, [_vp, _vp]),
     "sr_op_conv3x3_wgrad_noalloc": (C.c_int, [C.c_int] * 7 + [_vp] * 5),
     "sr_bench_conv": (C.c_int, [C.c_int] * 10 + [C.POINTER(C.c_float)]),
 }
@@ -255,6 +263,11 @@ class Context:
         out = np.empty(hs, np.float32)
         _check(lib().sr_step_hr_warp(self._h, B, _ptr(lr_t), _ptr(lr_tm1), _ptr(est_tm1), _ptr(out)), self._h)
         return out
+
+    def set_vgg(self, vgg):
+        """Attach (or, with None, detach) a Vgg19 to this TecoGAN context: the combined step then evaluates the four perceptual terms."""
+        _check(lib().sr_tecogan_set_vgg(self._h, vgg._h if vgg is not None else None), self._h)
+        self._vgg = vgg
 
     def clip_begin(self, B):
         self._clip_B = int(B)
@@ -521,6 +534,64 @@ class Discriminator:
             out[name] = np.asarray(flat[o:o + a.size]).reshape(a.shape)
             o += a.size
         return out
+
+
+class Vgg19:
+    """The VGG19 feature extractor of TecoGAN's four perceptual terms (reference TecoGAN.py:867-901) for HR images of
+    (H, W, 3): weights from the caller (32 arrays in Keras order), losses and the gradient with respect to the estimate.
+    Attach it to a TecoGAN Context with ``ctx.set_vgg(v)``; detach (``ctx.set_vgg(None)``) before closing it."""
+
+    def __init__(self, H, W, max_batch=1, dtype="fp32", device=0):
+        self.H, self.W, self.max_batch, self.device = int(H), int(W), int(max_batch), int(device)
+        self.dtype = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+        self._h = _vp()
+        rc = lib().sr_vgg_create(C.byref(self._h), device, H, W, max_batch, self.dtype)
+        if rc:
+            self._h = None
+            self._raise(rc)
+
+    def _raise(self, rc):
+        msg = lib().sr_vgg_last_error(self._h).decode("utf-8", "replace")
+        raise (ValueError if rc in (-1, -2, -3) else RuntimeError)(msg)
+
+    def _check(self, rc):
+        if rc:
+            self._raise(rc)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sr_vgg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_weights(self, tensors):
+        """tensors: 32 arrays, or an ordered mapping / iterable of (name, array), in Keras' VGG19 order
+        (block1_conv1 kernel, bias, ... block5_conv4 kernel, bias)."""
+        items = list(tensors.values()) if hasattr(tensors, "values") else [t[1] if isinstance(t, tuple) else t for t in tensors]
+        if len(items) != lib().sr_vgg_tensor_count():
+            raise ValueError(f"VGG19 (include_top=False) has 32 weight tensors, got {len(items)}")
+        for i, arr in enumerate(items):
+            a = _f32(arr)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            self._check(lib().sr_vgg_set_tensor(self._h, i, _ptr(a), shape, a.ndim))
+        self._check(lib().sr_vgg_commit(self._h))
+
+    def loss_grads(self, y_true, y_pred, weights=(3e-5, 1.4e-6, 6e-6, 2e-3), want_grad=True):
+        """-> ([vgg_22, vgg_34, vgg_44, vgg_54] unweighted, gradient of sum w_k loss_k w.r.t. y_pred or None)."""
+        y_true, y_pred = _f32(y_true), _f32(y_pred)
+        B = y_true.shape[0]
+        if y_true.shape != (B, self.H, self.W, 3) or y_pred.shape != y_true.shape:
+            raise ValueError(f"expected two arrays of shape {(B, self.H, self.W, 3)}")
+        w = (C.c_float * 4)(*[float(x) for x in weights])
+        losses = (C.c_float * 4)()
+        g = np.empty_like(y_pred) if want_grad else None
+        self._check(lib().sr_vgg_loss_grads(self._h, B, _ptr(y_true), _ptr(y_pred), w, losses, _ptr(g) if want_grad else None))
+        return [float(x) for x in losses], g
 
 
 def tecogan_grads(ctx, disc, lr_t, lr_tm1, est_tm1, next_est, next_hat_est, bic_past, bic_pres, bic_fut, hr_t, d_targets, pp_target,

@@ -293,3 +293,42 @@ def test_tecogan_adversarial_stage(tmp_path, weights7):
     for (n, a), (_, cur) in zip(saved, t.discriminator.named_weights()):
         np.testing.assert_array_equal(a, cur)
     assert (tmp_path / 'Samples' / 'Sample_1.npy').exists()
+
+
+def test_tecogan_perceptual_terms_from_a_weight_file(tmp_path, weights7):
+    """train.vgg19_weights (SURVEY.md section 8 f rank 3, first branch): the 32 VGG19 tensors come from a file -- here seeded
+    stand-ins, the ImageNet weights are a download -- and the adversarial iteration, both as one native call and through the
+    five Keras-shaped model calls, reports the four perceptual terms; vgg_22 .. vgg_54 are callable like the reference's."""
+    from oracle import ref_disc as rd
+    from oracle import ref_vgg as rv
+    import weights_io
+    vggw = rv.make_vgg_weights(3)
+    weights_io.write_tensors(str(tmp_path / 'vgg19.npz'), list(vggw.items()))
+    from TecoGAN import TecoGAN
+    cfg = {'root_dir': str(tmp_path), 'dtype': 'fp32', 'data': {'rows': 1, 'cols': 1, 'videos': str(tmp_path / 'clips')},
+           'cnn': {'model': 'tecogan', 'pretrained_model': 'w.npz'}, 'eval': {'output_dir': str(tmp_path / 'out')},
+           'train': {'vgg19_weights': 'vgg19.npz'}}
+    weights_io.write_tensors(str(tmp_path / 'w.npz'), list(weights7.items()))
+    losses = {}
+    for mode in ('native', 'keras'):
+        t = TecoGAN((16, 16, 3), (64, 64, 3), str(tmp_path), cfg)
+        t.build()
+        t._load_pretrained()
+        assert len(t.tecogan.vgg_weights) == 32
+        t.discriminator.set_weights(list(rd.make_disc_weights(9, 64, 64).values()))     # a fresh model draws random weights
+        t.step_by_step = mode == 'keras'
+        hr = rn.synth_clip(41, 4, 64, 64, scale=4)[None]
+        losses[mode] = t.gan_iteration(hr)
+        b = t._last_gan_batch
+    assert min(losses['native'][7:11]) > 0
+    assert np.allclose(losses['native'], losses['keras'], rtol=1e-5, atol=1e-9)
+    # the loss functions themselves, on the last batch's (hr, est): the oracle's values
+    want, _ = rv.vgg_loss_and_grad(vggw, b['hr'], b['est'])
+    got = [t.vgg_22(b['hr'], b['est']), t.vgg_34(b['hr'], b['est']), t.vgg_44(b['hr'], b['est']), t.vgg_54(b['hr'], b['est'])]
+    assert np.allclose(got, want, rtol=1e-4)
+    # without the file: 0, as before
+    cfg2 = dict(cfg, train={})
+    t0 = TecoGAN((16, 16, 3), (64, 64, 3), str(tmp_path), cfg2)
+    t0.build()
+    t0._load_pretrained()
+    assert t0.gan_iteration(hr)[7:11] == [0.0] * 4

@@ -283,7 +283,13 @@ def test_out_of_scope_stages_say_so():
         m.run()
     t = TecoGAN((16, 16, 3), (64, 64, 3), '/tmp/o', dict(CFG))
     with pytest.raises(NotImplementedError, match='ImageNet'):
-        t.vgg_54(None, None)                                         # perceptual losses: the weights are a download
+        t.vgg_54(None, None)                                         # perceptual losses: the weights are a download ...
+    import layers
+    tm = layers.TecoGANModel(None, None)
+    with pytest.raises(ValueError, match='32 weight tensors'):
+        tm.set_vgg_weights([np.zeros((3, 3, 3, 64))])               # ... unless train.vgg19_weights supplies all 32 tensors
+    tm.set_vgg_weights(None)
+    assert tm.vgg_weights is None
     assert [TecoGAN.gen_learning_rate(i) for i in (0, 49999, 50000, 100000, 10 ** 6)] == [1e-4, 1e-4, 5e-5, 2.5e-5, 2.5e-5]
 
 
