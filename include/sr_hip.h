@@ -38,7 +38,11 @@ enum sr_status {
 enum sr_dtype {
     SR_FP32 = 0,    /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 activations        */
     SR_BF16 = 1,    /* bf16 MFMA, bf16 activations in HBM, fp32 accumulate / epilogue     */
-    SR_BF16X3 = 2   /* fp32 activations, operands split hi+lo bf16, 3 bf16 MFMAs/product  */
+    SR_BF16X3 = 2,  /* fp32 activations, operands split hi+lo bf16, 3 bf16 MFMAs/product  */
+    SR_F16MX6 = 3   /* SR_BF16X3, except SRNet's 20 residual-block convs on the split-planar path: product = f16*f16 +
+                     * two MX-scaled FP6 (E2M3, E8M0 scale per 32 channels) cross terms, activations stored f16 + FP6 residue
+                     * (conv_trunk6.hip).  Same 1e-3 bar as the others; weights changed by sr_train_apply
+                     * put the ctx back on the SR_BF16X3 kernels until the next sr_commit_weights */
 };
 
 enum sr_model { SR_FRVSR = 0, SR_TECOGAN = 1 };
@@ -172,6 +176,12 @@ int sr_op_conv3x3(int device, int dtype, int B, int H, int W, int Cin, int Cout,
  * w (3,3,Cout,Cin); out (B,2H,2W,Cout). */
 int sr_op_convT3x3s2(int device, int dtype, int B, int H, int W, int Cin, int Cout,
                      const float* x, const float* w, const float* bias, int act, float* out);
+/* The same layer for 64 -> 64 channels in SR_F16MX6 arithmetic (conv_trunk6.hip; reference layers.py:58-62, one conv of a residual
+ * block): x, res, out (B,H,W,64).  A ReLU layer (relu = 1, res NULL) or a residual layer (relu = 0, res: out = res + conv(x)).
+ * mode 0: the result as stored in the mx6 format; 1: residual layer writing split-planar records (the trunk's last layer);
+ * 2 / 3: no conv -- x after a round trip through the format (the stored value / its FP6 image alone; w, bias may be NULL). */
+int sr_op_conv3x3_mx6(int device, int B, int H, int W, const float* x, const float* w, const float* bias, int relu,
+                      const float* res, int mode, float* out);
 /* MaxPool2D(2x2, padding='same'): reference layers.py:31.  out (B,ceil(H/2),ceil(W/2),C). */
 int sr_op_maxpool2(int device, int B, int H, int W, int C, const float* x, float* out);
 /* UpSampling2D(size=s, interpolation='bilinear') = TF1 legacy resize: reference

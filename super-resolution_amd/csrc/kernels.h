@@ -90,6 +90,15 @@ struct TrunkArgs {
 hipError_t launch_trunk_conv(TrunkArgs a, hipStream_t s);
 hipError_t launch_trunk_convT(TrunkArgs a, hipStream_t s);   // conv2d_transpose_1, split-planar in and out
 size_t trunk_weight_bytes();
+// the residual blocks' convs in f16 + MX FP6 arithmetic on "mx6" activations (conv_trunk6.hip): a.in / a.res / a.out mx6, or a.out
+// split-planar (out_split: the trunk's last layer); a.wpack = trunk6_pack_weights()
+hipError_t launch_trunk6_conv(TrunkArgs a, int out_split, hipStream_t s);
+hipError_t launch_split_to_mx6(const void* in, void* out, int B, int H, int W, hipStream_t s);
+hipError_t launch_nhwc_to_mx6(const float* x, void* out, int B, int H, int W, hipStream_t s);                // x [B,H,W,64]
+hipError_t launch_mx6_to_nhwc(const void* in, float* y, int B, int H, int W, int which, hipStream_t s);      // which 0: hi + lo6, 1: x6
+hipError_t launch_split_to_nhwc(const void* in, float* y, int B, int H, int W, hipStream_t s);
+size_t trunk6_weight_bytes();
+void trunk6_pack_weights(const float* w, unsigned char* out);   // host: Keras kernel (3, 3, 64, 64) -> trunk6_weight_bytes() bytes
 // SRNet's x4 tail on a split-planar input (conv_tail.hip): conv2d_transpose_2 + ReLU + conv2d_36's tap projection and nine-tap
 // sum; interior pixels of the 16 x 64 output tiles go to `img`, the tiles' border rings as partial sums to `S` (launch_gather_fix
 // with th = 16 finishes them)

@@ -244,7 +244,7 @@ int upload_alt(sr_ctx* c, ConvLayer& L, size_t bytes, const float* w) {
 }
 
 void free_layer(ConvLayer& L) {
-    void* ps[] = {L.d_w, L.d_bias, L.d_proj, L.d_ents, L.d_proj_ents, L.d_w2, L.d_ents2, L.d_w3, L.d_ents3};
+    void* ps[] = {L.d_w, L.d_bias, L.d_proj, L.d_ents, L.d_proj_ents, L.d_w2, L.d_ents2, L.d_w3, L.d_ents3, L.d_w6};
     for (void* p : ps)
         if (p) (void)hipFree(p);
     L.d_w = nullptr;
@@ -256,6 +256,7 @@ void free_layer(ConvLayer& L) {
     L.d_ents2 = nullptr;
     L.d_w3 = nullptr;
     L.d_ents3 = nullptr;
+    L.d_w6 = nullptr;
 }
 
 // Tap-projection weights for conv_mfma.hip epilogue_proj: the following conv's kernel w[3,3,64,cout<=3]
@@ -640,6 +641,30 @@ int run_srnet(sr_ctx* c, int B, float* d_out, bool split) {
                 LAUNCHCHK(c, name, launch_trunk_conv(ta, st));
                 return SR_OK;
             };
+            if (c->trunk_mx6 && c->mx6_valid) {
+                // head (bf16x3) -> sy, converted to mx6 in sx; the blocks ping-pong sx / sy in mx6; the last conv writes
+                // split-planar records again, into s_in (not in place: its output planes are other workgroups' residual planes)
+                auto trunk6 = [&](const ConvLayer& L, const unsigned char* in, unsigned char* out, const unsigned char* res, int relu,
+                                  int out_split, const char* name) -> int {
+                    TrunkArgs ta = {in, out, res, (const unsigned char*)L.d_w6, L.d_bias, (unsigned)tail, 0u, nb, H, W, relu, 0, 0, 0};
+                    const double px = (double)nb * H * W;
+                    ProfScope ps(c, name, px * 9.0 * L.cin * L.cout * 2.0, px * 256.0 * (res ? 3 : 2) + (double)trunk6_weight_bytes());
+                    if (tail + 4096 > 4294967295.0) return fail(c, SR_ERR_ARG, "%s: tensor too large for 32-bit offsets", name);
+                    LAUNCHCHK(c, name, launch_trunk6_conv(ta, out_split, st));
+                    return SR_OK;
+                };
+                int rc = trunk(c->srnet[0], s_in, sy, nullptr, 1, "srnet.head");
+                if (rc) return rc;
+                {
+                    ProfScope ps(c, "srnet.to_mx6", 0.0, (double)nb * H * W * 512.0);
+                    LAUNCHCHK(c, "srnet.to_mx6", launch_split_to_mx6(sy, sx, nb, H, W, st));
+                }
+                for (int r = 0; r < 10; ++r) {
+                    if ((rc = trunk6(c->srnet[1 + 2 * r], sx, sy, nullptr, 1, 0, "srnet.res6"))) return rc;
+                    if ((rc = trunk6(c->srnet[2 + 2 * r], sy, r == 9 ? s_in : sx, sx, 0, r == 9, "srnet.res6"))) return rc;
+                }
+                continue;
+            }
             int rc = trunk(c->srnet[0], s_in, sx, nullptr, 1, "srnet.head");
             if (rc) return rc;
             for (int r = 0; r < 10; ++r) {
@@ -663,19 +688,20 @@ int run_srnet(sr_ctx* c, int B, float* d_out, bool split) {
     // split && trunk_up1: conv2d_transpose_1 on conv_trunk.hip's transposed-conv kernel, split-planar in AND out (the input
     // staging of conv2d_transpose_2 is then a plain copy); SR_NO_TRUNK_UP1=1: the generic transposed-conv kernel, fp32 NHWC out
     const bool up1_split = split && c->trunk_up1;
+    const char* trunk_out = split && c->trunk_mx6 && c->mx6_valid ? "s_in" : "sx";   // where the loop above left the trunk's output
     int rc;
     if (up1_split) {
         const ConvLayer& L = c->srnet[21];
         const size_t left = (size_t)(c->max_batch - c->lane_b0);
         const size_t tail_in = left * H * W * 256, tail_out = 4 * tail_in;
         if (tail_out + 4096 > 4294967295.0) return fail(c, SR_ERR_ARG, "srnet.up1: tensor too large for 32-bit offsets");
-        TrunkArgs ta = {(const unsigned char*)b("sx"), (unsigned char*)b("up1"), nullptr, (const unsigned char*)L.d_w2, L.d_bias,
+        TrunkArgs ta = {(const unsigned char*)b(trunk_out), (unsigned char*)b("up1"), nullptr, (const unsigned char*)L.d_w2, L.d_bias,
                         (unsigned)tail_in, (unsigned)tail_out, B, H, W, 1, 0, 0, 0};
         const double px = (double)B * H * W;
         ProfScope ps(c, "srnet.up1", px * 9.0 * 64 * 64 * 2.0, px * 256.0 * 5 + (double)trunk_weight_bytes());
         LAUNCHCHK(c, "srnet.up1", launch_trunk_convT(ta, st));
     } else {
-        ConvIO up1 = {b("sx"), H, W, b("up1"), 64, 64, af, nullptr, 0, A_RELU, split ? 1 : c->planar_trunk, 0};
+        ConvIO up1 = {b(trunk_out), H, W, b("up1"), 64, 64, af, nullptr, 0, A_RELU, split ? 1 : c->planar_trunk, 0};
         up1.in_split = split ? 1 : 0;
         rc = run_conv(c, P, st, c->srnet[21], B, up1, "srnet.up1");
         if (rc) return rc;
@@ -893,7 +919,9 @@ static int create_common(sr_ctx** out, int device, int h_in, int w_in, int ch, i
     if (h_in < 2 || w_in < 2) return fail(nullptr, SR_ERR_SHAPE, "LR tile %dx%d: dense_image_warp needs at least 2x2", h_in, w_in);
     const int h = round_up(h_in, 8), w = round_up(w_in, 8);
     if (max_batch < 1) return fail(nullptr, SR_ERR_ARG, "max_batch must be >= 1");
-    if (dtype < 0 || dtype > 2) return fail(nullptr, SR_ERR_ARG, "dtype must be 0 (fp32), 1 (bf16) or 2 (bf16x3)");
+    if (dtype < 0 || dtype > 3) return fail(nullptr, SR_ERR_ARG, "dtype must be 0 (fp32), 1 (bf16), 2 (bf16x3) or 3 (f16mx6)");
+    const bool mx6 = dtype == SR_F16MX6;
+    if (mx6) dtype = SR_BF16X3;      // everything but the residual blocks' kernels
     if (model != SR_FRVSR && model != SR_TECOGAN) return fail(nullptr, SR_ERR_ARG, "model must be 0 (frvsr) or 1 (tecogan)");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -919,6 +947,8 @@ static int create_common(sr_ctx** out, int device, int h_in, int w_in, int ch, i
     if (const char* e = getenv("SR_TAIL")) c->tail_kernel = atoi(e);
     if (const char* e = getenv("SR_SPLIT_TRUNK")) c->split_trunk = atoi(e);
     if (const char* e = getenv("SR_FNET")) c->fnet_split = atoi(e);
+    c->trunk_mx6 = mx6 ? 1 : 0;
+    if (const char* e = getenv("SR_MX6")) c->trunk_mx6 = (dtype == SR_BF16X3 && atoi(e)) ? 1 : 0;
     int rc = SR_OK;
     auto bail = [&](int code) {
         g_err = c->err;
@@ -1087,6 +1117,17 @@ int sr_commit_weights(sr_ctx* c) {
             int rc = upload_alt(c, L, bytes, c->tensors[28 + 2 * i].data.data());
             if (rc) return rc;
         }
+    }
+    c->mx6_valid = false;
+    if (c->prec == P_BF16X3 && c->split_trunk && c->trunk_mx6) {   // conv_trunk6.hip: f16 + FP6 packing of the residual blocks' convs
+        std::vector<unsigned char> packed(trunk6_weight_bytes());
+        for (int i = 1; i <= 20; ++i) {
+            ConvLayer& L = c->srnet[i];
+            trunk6_pack_weights(c->tensors[28 + 2 * i].data.data(), packed.data());
+            if (!L.d_w6) HIPCHK(c, hipMalloc(&L.d_w6, packed.size()));
+            HIPCHK(c, hipMemcpy(L.d_w6, packed.data(), packed.size(), hipMemcpyHostToDevice));
+        }
+        c->mx6_valid = true;
     }
     if (c->prec == P_BF16X3 && c->fnet_split) {   // conv_fnet.hip: second packing of FNet's 13 MFMA convs (conv2d_14 stays on the taps-in-N kernel)
         for (int i = 0; i < 13; ++i) {
@@ -1438,6 +1479,60 @@ int sr_op_convT3x3s2(int device, int dtype, int B, int H, int W, int Cin, int Co
     return conv_op(device, dtype, M_CONVT, B, H, W, Cin, Cout, x, w, bias, act, nullptr, out);
 }
 
+int sr_op_conv3x3_mx6(int device, int B, int H, int W, const float* x, const float* w, const float* bias, int relu, const float* res,
+                      int mode, float* out) {
+    int rc = op_prologue(device);
+    if (rc) return rc;
+    if (!x || !out) return fail(nullptr, SR_ERR_ARG, "NULL tensor pointer");
+    if (B < 1 || H < 1 || W < 1) return fail(nullptr, SR_ERR_ARG, "non-positive dimension");
+    if (mode < 0 || mode > 4) return fail(nullptr, SR_ERR_ARG, "mode must be 0..4");
+    const size_t npix = (size_t)B * H * W, bytes = npix * 256;
+    if ((double)bytes + 4096.0 > 4294967295.0) return fail(nullptr, SR_ERR_ARG, "tensor too large for 32-bit offsets");
+    DevBufs d;
+    float* d_f = (float*)d.get(npix * 64 * 4);
+    unsigned char* d_in = (unsigned char*)d.get(bytes + 4096);
+    unsigned char* d_o = (unsigned char*)d.get(bytes + 4096);
+    unsigned char* d_r = (unsigned char*)d.get(bytes + 4096);
+    unsigned char* d_w = (unsigned char*)d.get(trunk6_weight_bytes());
+    float* d_b = (float*)d.get(64 * 4);
+    if (!d_f || !d_in || !d_o || !d_r || !d_w || !d_b) return fail(nullptr, SR_ERR_HIP, "hipMalloc failed");
+    HIPCHK(nullptr, hipMemset(d_in + bytes, 0, 4096));
+    HIPCHK(nullptr, hipMemset(d_o + bytes, 0, 4096));
+    HIPCHK(nullptr, hipMemset(d_r + bytes, 0, 4096));
+    HIPCHK(nullptr, hipMemcpy(d_f, x, npix * 64 * 4, hipMemcpyHostToDevice));
+    LAUNCHCHK(nullptr, "nhwc_to_mx6", launch_nhwc_to_mx6(d_f, d_in, B, H, W, nullptr));
+    if (mode == 4) {     // the raw records (B x 4 planes x H x W x 64 bytes = as many bytes as `out` has)
+        HIPCHK(nullptr, hipDeviceSynchronize());
+        HIPCHK(nullptr, hipMemcpy(out, d_in, bytes, hipMemcpyDeviceToHost));
+        return SR_OK;
+    }
+    if (mode >= 2) {     // the format alone: 2 = the stored value (hi + lo6), 3 = the x6 plane
+        LAUNCHCHK(nullptr, "mx6_to_nhwc", launch_mx6_to_nhwc(d_in, d_f, B, H, W, mode - 2, nullptr));
+        HIPCHK(nullptr, hipDeviceSynchronize());
+        HIPCHK(nullptr, hipMemcpy(out, d_f, npix * 64 * 4, hipMemcpyDeviceToHost));
+        return SR_OK;
+    }
+    if (!w || !bias) return fail(nullptr, SR_ERR_ARG, "NULL tensor pointer");
+    if ((relu != 0) == (res != nullptr)) return fail(nullptr, SR_ERR_ARG, "a ReLU layer (relu, no res) or a residual layer (res, no relu)");
+    if (mode == 1 && !res) return fail(nullptr, SR_ERR_ARG, "split-planar output is the residual layer's");
+    if (res) {
+        HIPCHK(nullptr, hipMemcpy(d_f, res, npix * 64 * 4, hipMemcpyHostToDevice));
+        LAUNCHCHK(nullptr, "nhwc_to_mx6", launch_nhwc_to_mx6(d_f, d_r, B, H, W, nullptr));
+    }
+    std::vector<unsigned char> packed(trunk6_weight_bytes());
+    trunk6_pack_weights(w, packed.data());
+    HIPCHK(nullptr, hipMemcpy(d_w, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    HIPCHK(nullptr, hipMemcpy(d_b, bias, 64 * 4, hipMemcpyHostToDevice));
+    // a residual layer of the trunk updates x in place; the split-planar output cannot (conv_trunk6.hip)
+    TrunkArgs ta = {d_in, (res && mode == 0) ? d_r : d_o, res ? d_r : nullptr, d_w, d_b, (unsigned)bytes, 0u, B, H, W, relu, 0, 0, 0};
+    LAUNCHCHK(nullptr, "trunk6", launch_trunk6_conv(ta, mode == 1, nullptr));
+    if (mode == 1) LAUNCHCHK(nullptr, "split_to_nhwc", launch_split_to_nhwc(ta.out, d_f, B, H, W, nullptr));
+    else LAUNCHCHK(nullptr, "mx6_to_nhwc", launch_mx6_to_nhwc(ta.out, d_f, B, H, W, 0, nullptr));
+    HIPCHK(nullptr, hipDeviceSynchronize());
+    HIPCHK(nullptr, hipMemcpy(out, d_f, npix * 64 * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
 int sr_op_maxpool2(int device, int B, int H, int W, int C, const float* x, float* out) {
     if (B < 1 || H < 1 || W < 1 || C < 1) return fail(nullptr, SR_ERR_ARG, "non-positive dimension");
     const size_t n_in = (size_t)B * H * W * C, n_out = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * C;
@@ -1501,6 +1596,46 @@ int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, in
     if (rc) return rc;
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || iters < 1 || !ms_per_launch)
         return fail(nullptr, SR_ERR_ARG, "bad argument");
+    if (dtype == SR_F16MX6) {   // one residual-block conv on conv_trunk6.hip, mx6 in and out, random data
+        if (transposed || Cin != 64 || Cout != 64) return fail(nullptr, SR_ERR_ARG, "f16mx6: the 64 -> 64 conv only");
+        const size_t npix = (size_t)B * H * W, bytes = npix * 256;
+        if ((double)bytes + 4096.0 > 4294967295.0) return fail(nullptr, SR_ERR_ARG, "tensor too large for 32-bit offsets");
+        DevBufs d;
+        float* d_f = (float*)d.get(npix * 64 * 4);
+        unsigned char* bufs[2] = {(unsigned char*)d.get(bytes + 4096), (unsigned char*)d.get(bytes + 4096)};
+        unsigned char* d_w = (unsigned char*)d.get(trunk6_weight_bytes());
+        float* d_b = (float*)d.get(64 * 4);
+        if (!d_f || !bufs[0] || !bufs[1] || !d_w || !d_b) return fail(nullptr, SR_ERR_HIP, "hipMalloc failed");
+        std::vector<float> w((size_t)9 * 64 * 64), bias(64, 0.01f), x(npix * 64);
+        uint32_t st = 12345u;
+        auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 65536.0f - 0.5f; };
+        for (auto& v : w) v = rnd() * 0.1f;
+        for (auto& v : x) v = rnd();
+        std::vector<unsigned char> packed(trunk6_weight_bytes());
+        trunk6_pack_weights(w.data(), packed.data());
+        HIPCHK(nullptr, hipMemcpy(d_w, packed.data(), packed.size(), hipMemcpyHostToDevice));
+        HIPCHK(nullptr, hipMemcpy(d_b, bias.data(), 64 * 4, hipMemcpyHostToDevice));
+        HIPCHK(nullptr, hipMemcpy(d_f, x.data(), npix * 64 * 4, hipMemcpyHostToDevice));
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(nullptr, hipMemset(bufs[k] + bytes, 0, 4096));
+            LAUNCHCHK(nullptr, "nhwc_to_mx6", launch_nhwc_to_mx6(d_f, bufs[k], B, H, W, nullptr));
+        }
+        TrunkArgs ta = {bufs[0], bufs[1], residual ? bufs[1] : nullptr, d_w, d_b, (unsigned)bytes, 0u, B, H, W, residual ? 0 : 1, 0, 0, 0};
+        hipEvent_t e0, e1;
+        HIPCHK(nullptr, hipEventCreate(&e0));
+        HIPCHK(nullptr, hipEventCreate(&e1));
+        for (int i = 0; i < 3; ++i) LAUNCHCHK(nullptr, "trunk6", launch_trunk6_conv(ta, 0, nullptr));
+        HIPCHK(nullptr, hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) LAUNCHCHK(nullptr, "trunk6", launch_trunk6_conv(ta, 0, nullptr));
+        HIPCHK(nullptr, hipEventRecord(e1, nullptr));
+        HIPCHK(nullptr, hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(nullptr, hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *ms_per_launch = ms / iters;
+        return SR_OK;
+    }
     if (dtype < 0 || dtype > 2) return fail(nullptr, SR_ERR_ARG, "bad dtype");
     const int mode = transposed ? M_CONVT : M_CONV;
     ConvLayer L;

@@ -50,6 +50,7 @@ struct ConvLayer {
     void* d_w3 = nullptr;
     std::vector<PackEnt> ents3;
     PackEnt* d_ents3 = nullptr;
+    void* d_w6 = nullptr;   // SR_F16MX6, SRNet convs 1..20: trunk6_pack_weights (conv_trunk6.hip)
     double wbytes = 0;
     // packing lists (kept for the device re-pack)
     std::vector<PackEnt> ents, proj_ents;
@@ -107,6 +108,10 @@ struct sr_ctx {
     int fuse_gather = 1;                 // SRNet tail: conv2d_36's tap sum inside conv2d_transpose_2's kernel (SR_NO_FUSE_GATHER=1: tap_gather_kernel)
     int fuse_pool = 1;                   // FNet: MaxPooling2D in the producing conv's epilogue (SR_NO_FUSE_POOL=1: separate kernel)
     bool step_split = false;   // the step being enqueued uses it
+    // dtype SR_F16MX6 (or SR_MX6=1 on a bf16x3 ctx): the residual blocks of a split-planar step run on conv_trunk6.hip.
+    // mx6_valid: the d_w6 packings match the weights (sr_commit_weights sets it, a training update clears it)
+    int trunk_mx6 = 0;
+    bool mx6_valid = false;
     // bf16x3 only: FNet on conv_fnet.hip with split-planar activations: 1 = steps of more than 65,536 pixels, 2 = always
     // (SR_FNET=2, tests), 0 = never (SR_FNET=0: conv_mfma.hip)
     int fnet_split = 1;

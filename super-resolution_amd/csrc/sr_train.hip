@@ -632,6 +632,7 @@ int sr_train_apply(sr_ctx* c, const float* d_grads, float grad_scale, float lr, 
     LAUNCHCHK(c, "adam", launch_adam(T->d_params, T->d_m, T->d_v, d_grads ? d_grads : T->d_grad, T->nparams, (float)lr_t, beta1,
                                      beta2, eps, grad_scale, c->stream));
     T->host_stale = true;
+    c->mx6_valid = false;   // SR_F16MX6: the host-packed conv_trunk6.hip weights are stale; steps run on the bf16x3 kernels
     return repack_all(c);
 }
 
@@ -1080,6 +1081,7 @@ static int tecogan_adam(sr_ctx* c, sr_disc* d, const float* d_gen_grads, const f
     LAUNCHCHK(c, "adam", launch_adam(T->d_params, T->d_m2, T->d_v2, d_gen_grads ? d_gen_grads : T->d_grad, T->nparams, (float)lr_t, beta1,
                                      beta2, eps, d_gen_grads ? grad_scale : 1.f, c->stream));
     T->host_stale = true;
+    c->mx6_valid = false;
     int rc = repack_all(c);
     if (rc) return rc;
     if (train_disc) {

@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsr_hip.so")
 
 FP32, BF16, BF16X3 = 0, 1, 2
-DTYPES = {"fp32": FP32, "float32": FP32, "bf16": BF16, "bfloat16": BF16, "bf16x3": BF16X3}
+F16MX6 = 3
+DTYPES = {"fp32": FP32, "float32": FP32, "bf16": BF16, "bfloat16": BF16, "bf16x3": BF16X3, "f16mx6": F16MX6, "mx6": F16MX6}
 FRVSR, TECOGAN = 0, 1
 ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2, "leaky_relu": 2, "tanh": 3, "clip01": 4}
 
@@ -54,6 +55,7 @@ SIGNATURES = {
     "sr_profile_reset": (C.c_int, [_vp]),
     "sr_op_conv3x3": (C.c_int, [C.c_int] * 7 + [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "sr_op_convT3x3s2": (C.c_int, [C.c_int] * 7 + [_vp, _vp, _vp, C.c_int, _vp]),
+    "sr_op_conv3x3_mx6": (C.c_int, [C.c_int] * 4 + [_vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp]),
     "sr_op_maxpool2": (C.c_int, [C.c_int] * 5 + [_vp, _vp]),
     "sr_op_resize_bilinear": (C.c_int, [C.c_int] * 6 + [_vp, _vp]),
     "sr_op_warp": (C.c_int, [C.c_int] * 5 + [_vp, _vp, _vp]),
@@ -657,6 +659,24 @@ def conv3x3(x, w, b, act="none", res=None, dtype="fp32", device=0):
     r = _f32(res) if res is not None else None
     _check(lib().sr_op_conv3x3(device, DTYPES[dtype], B, H, W, Cin, Cout, _ptr(x), _ptr(w), _ptr(b), ACT[act],
                                _ptr(r) if r is not None else None, _ptr(out)))
+    return out
+
+
+def conv3x3_mx6(x, w=None, b=None, relu=False, res=None, mode=0, device=0):
+    """One 64 -> 64 conv of a residual block in f16mx6 arithmetic (include/sr_hip.h sr_op_conv3x3_mx6).  mode 0: result read back from
+    the mx6 format, 1: residual layer through split-planar records, 2 / 3: x through the format alone (stored value / FP6 image)."""
+    x = _f32(x)
+    B, H, W, Cc = x.shape
+    if Cc != 64:
+        raise ValueError(f"64 channels, got {Cc}")
+    out = np.empty((B, H, W, 64), np.float32)
+    w = _f32(w) if w is not None else None
+    b = _f32(b) if b is not None else None
+    r = _f32(res) if res is not None else None
+    if w is not None and (w.shape != (3, 3, 64, 64) or b is None or b.shape != (64,)):
+        raise ValueError("kernel (3, 3, 64, 64) and bias (64,)")
+    _check(lib().sr_op_conv3x3_mx6(device, B, H, W, _ptr(x), _ptr(w) if w is not None else None, _ptr(b) if b is not None else None,
+                                   1 if relu else 0, _ptr(r) if r is not None else None, mode, _ptr(out)))
     return out
 
 

@@ -9,7 +9,7 @@ Makefile saves them per object) and fails the build when one of those kernels ha
 import re
 import sys
 
-GUARDED = ("trunk_conv_kernel", "trunk_convT_kernel", "tail_kernel", "fnet_conv_kernel", "convT3x3_gather_kernel")
+GUARDED = ("trunk_conv_kernel", "trunk_convT_kernel", "trunk6_conv_kernel", "tail_kernel", "fnet_conv_kernel", "convT3x3_gather_kernel")
 
 
 def main(paths):
