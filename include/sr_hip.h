@@ -138,6 +138,15 @@ int sr_u8_wait(sr_ctx* ctx, int keep_in_flight);
  * sr_clip_push* produced -- of clips first .. first + n - 1 to est (n,4h,4w,3) float32 on the host and returns when
  * they have landed.  For drivers that take the frames as uint8 (sr_clip_push_u8) and need the float values of a few. */
 int sr_clip_read_est(sr_ctx* ctx, int first, int n, float* est);
+/* The same read-back beside the NEXT step instead of in front of it (the eval loop's metric frames: 177 MB per 16 clips of 720p
+ * would otherwise hold the device for ~7 ms).  _begin enqueues the copy of the newest estimates (clips [first, first + n)) into
+ * `est` -- page-locked memory (sr_host_alloc), or the copy is not asynchronous -- on a stream of its own, ordered after the
+ * step that produced them; the caller may push the next frame at once.  The push after that one waits on the device until the
+ * copy is over (it overwrites the buffer being read).  _end blocks the host until `est` is valid.  One read-back at a time:
+ * _begin before the previous _end is SR_ERR_STATE, as is _end without _begin.  No counterpart in the reference (its
+ * predict_on_batch returns every float frame to the host, FRVSR.py:292-296). */
+int sr_clip_read_est_begin(sr_ctx* ctx, int first, int n, float* est);
+int sr_clip_read_est_end(sr_ctx* ctx);
 
 /* Page-locked host memory for the buffers sr_clip_push_u8 copies from / into asynchronously (Keras manages its own host
  * staging inside predict; no reference counterpart).  bytes > 0; sr_host_free(NULL) is a no-op. */

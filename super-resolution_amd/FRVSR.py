@@ -279,6 +279,23 @@ class FrameRecurrentVideoSR(object):
                 if t < Ts[k]:
                     outs[k][t] = merge_tiles(src[k * tiles:(k + 1) * tiles], rows, cols)
 
+        def score(est_f, t, active, ms):     # PSNR / SSIM rows of metric frame t (FRVSR.py:320-339); host time, not loop time
+            t1 = now()
+            for k in active:
+                est = merge_tiles(est_f[k * tiles:(k + 1) * tiles], rows, cols)
+                hr = hr_clips[k][t]
+                p, q = psnr(hr, est), ssim(hr, est)
+                stats[k]['psnr'].append(p)
+                stats[k]['ssim'].append(q)
+                bic = sr_hip.cubic_upscale4(lr_clips[k][t:t + 1], device=self.core.device)[0]   # FRVSR.py:304,322,328
+                stats[k]['bic_psnr'].append(psnr(bic, hr))
+                stats[k]['bic_ssim'].append(ssim(bic, hr))
+                if metrics_file is not None:    # the reference's row (FRVSR.py:339)
+                    metrics_file.write('Video:\t%s\tFrame:\t%d\tInference time:\t%d\tPSNR:\t%f\tSSIM:\t%f\n'
+                                       % (names[k], t, ms / len(active), p, q))
+            timing['metrics_s'] += (now() - t1).total_seconds()
+
+        pending = None           # (frame, its active clips, its ms): a float read-back in flight
         try:
             if slots == Tmax:
                 for t in range(Tmax):
@@ -293,38 +310,44 @@ class FrameRecurrentVideoSR(object):
                 ctx.u8_wait(1)
                 if slots != Tmax and t > 0:
                     consume(t - 1)
+                # metric frames (every 10th, FRVSR.py:320): the float estimates of frame t leave the device beside step t + 1
+                # (sr_clip_read_est_begin) and are scored one iteration later, or after the loop
                 est_f = None
-                if t % 10 == 0 and hr_clips is not None:
-                    est_f = ctx.clip_read_est(0, B, out=est_pin.a)
+                if pending is not None:
+                    ctx.clip_read_est_end()
+                    est_f, (tm, active_m, ms_m) = est_pin.a, pending
+                    pending = None
                 ms = (now() - t0).total_seconds() * 1000
+                if t % 10 == 0 and hr_clips is not None:
+                    ta = now()
+                    ctx.clip_read_est_begin(est_pin.a, 0, B)
+                    ms += (now() - ta).total_seconds() * 1000
+                    pending = (t, active, ms)
                 timing['loop_s'] += ms / 1000
                 timing['frames'] += len(active)
                 for k in active:
                     stats[k]['ms'].append(ms / len(active))
                 if est_f is not None:
-                    t1 = now()
-                    for k in active:
-                        est = merge_tiles(est_f[k * tiles:(k + 1) * tiles], rows, cols)
-                        hr = hr_clips[k][t]
-                        p, q = psnr(hr, est), ssim(hr, est)
-                        stats[k]['psnr'].append(p)
-                        stats[k]['ssim'].append(q)
-                        bic = sr_hip.cubic_upscale4(lr_clips[k][t:t + 1], device=self.core.device)[0]   # FRVSR.py:304,322,328
-                        stats[k]['bic_psnr'].append(psnr(bic, hr))
-                        stats[k]['bic_ssim'].append(ssim(bic, hr))
-                        if metrics_file is not None:    # the reference's row (FRVSR.py:339)
-                            metrics_file.write('Video:\t%s\tFrame:\t%d\tInference time:\t%d\tPSNR:\t%f\tSSIM:\t%f\n'
-                                               % (names[k], t, ms / len(active), p, q))
-                    timing['metrics_s'] += (now() - t1).total_seconds()
+                    score(est_f, tm, active_m, ms_m)
             t0 = now()
             ctx.u8_wait(0)
+            if pending is not None:
+                ctx.clip_read_est_end()
             timing['loop_s'] += (now() - t0).total_seconds()
+            if pending is not None:
+                score(est_pin.a, *pending)
+                pending = None
             if slots == Tmax:
                 for t in range(Tmax):
                     consume(t)
             else:
                 consume(Tmax - 1)
         finally:
+            if pending is not None:      # an exception between begin and end: the copy must be over before the slot is freed
+                try:
+                    ctx.clip_read_est_end()
+                except Exception:
+                    pass
             ctx.sync()
             lr_pin.close()
             out_pin.close()

@@ -205,10 +205,11 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
             pc.rh = pc.rl = u32x4{0u, 0u, 0u, 0u};
         }
     };
-    // the residual loads are older than the NDMA DMA instructions of the step that issued them
-    auto ep_wait = [&](Piece& pc, auto ndma) {
-        constexpr int N = decltype(ndma)::value;
-        if (RES && !(NOMEM & 4)) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(pc.rh), "+v"(pc.rl) : "n"(N));
+    // The residual loads of a piece are issued one plane step ahead (a load takes about 1.3 us under this kernel's traffic, a
+    // third of a step is 0.65 us: waited for in the step that issued them, every step of a residual layer stalled on them --
+    // tools/probe/trunk_ablate_b.py).  By the top of the next step they have landed: they are older than the DMA that step waits for.
+    auto ep_landed = [&](Piece& pc) {
+        if (RES && !(NOMEM & 4)) asm volatile("" : "+v"(pc.rh), "+v"(pc.rl));
     };
     auto ep_pair = [&](Piece& pc, float v0, float v1, int k) {
         if (RELU) {      // one v_max each (fmaxf() puts a canonicalising v_max in front: the accumulators may hold any bits); the
@@ -233,6 +234,8 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
     };
 
     f32x16 acc[2], fin[2];      // running tile; finished tile whose epilogue is being drained
+    Piece pcs[2];               // epilogue piece of this plane step / of the next one (its residual in flight)
+    ep_load(pcs[0], dump);      // piece 0 of the (empty) tile that drains under the first tile
     f32x4 shp[2][2] = {};       // NOMEM & 8 only
     Tile done;                  // where `fin` goes
     done.eoff[0] = done.eoff[1] = dump;
@@ -259,8 +262,12 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             __builtin_amdgcn_s_barrier();           // every wave's part landed; every wave is done reading the other buffer
             asm volatile("" ::: "memory");
-            Piece pc;
-            ep_load(pc, done.eoff[mbp] + (plp ? estep(done.eoff[mbp]) : 0u));     // before the DMA: older in the vmcnt queue
+            Piece& pc = pcs[C & 1];
+            {   // the next step's piece: C + 1 of the finished tile, or piece 0 of the tile being computed (finished by then)
+                constexpr int CN = (C + 1) & 3;
+                const unsigned base = C < 3 ? done.eoff[CN >> 1] : cur.eoff[0];
+                ep_load(pcs[(C + 1) & 1], base + ((CN & 1) ? estep(base) : 0u));   // before the DMA: older in the vmcnt queue
+            }
             if (C < 3) issue(cur, C + 1, (q + 1) & 1);
             else issue(nxt, 0, (q + 1) & 1);        // past the last tile: re-reads this tile's first plane, harmless
             const unsigned char* at = abuf + (q & 1) * TK::A_BYTES;
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
                     }
                 }
                 // the epilogue piece, spread over the taps: pair k under tap 3 + k, the stores under tap 7
-                if (tap == 3) ep_wait(pc, std::integral_constant<int, (NOMEM & 1) ? 0 : TK::PER_WAVE>{});
+                if (tap == 3) ep_landed(pc);
                 if (tap >= 3 && tap < 7) {
                     const int k = tap - 3;
                     ep_pair(pc, fin[mbp][8 * plp + 2 * k], fin[mbp][8 * plp + 2 * k + 1], k);
@@ -347,9 +354,10 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
-            Piece pc;
-            ep_load(pc, done.eoff[mb] + (pl ? estep(done.eoff[mb]) : 0u));
-            ep_wait(pc, std::integral_constant<int, 0>{});
+            Piece& pc = pcs[0];
+            if (mb + pl > 0) ep_load(pc, done.eoff[mb] + (pl ? estep(done.eoff[mb]) : 0u));   // piece 0 came with the last plane step
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ep_landed(pc);
 #pragma unroll
             for (int k = 0; k < 4; ++k) ep_pair(pc, fin[mb][8 * pl + 2 * k], fin[mb][8 * pl + 2 * k + 1], k);
             ep_store(pc);

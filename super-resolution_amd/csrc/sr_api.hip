@@ -890,6 +890,13 @@ void free_u8_path(sr_ctx* c) {
     c->copy_stream = nullptr;
     c->u8_ready = false;
     c->u8_pushes = 0;
+    if (c->est_stream) (void)hipStreamDestroy(c->est_stream);
+    if (c->ev_est_src) (void)hipEventDestroy(c->ev_est_src);
+    if (c->ev_est_done) (void)hipEventDestroy(c->ev_est_done);
+    c->est_stream = nullptr;
+    c->ev_est_src = c->ev_est_done = nullptr;
+    c->est_guard = 0;
+    c->est_pending = false;
 }
 
 }  // namespace srh
@@ -1234,6 +1241,8 @@ static int clip_push_common(sr_ctx* c, const float* lr_t, float* est_t, bool dev
     HIPCHK(c, hipSetDevice(c->device));
     const int B = c->clip_B;
     hipStream_t st = c->stream;
+    // sr_clip_read_est_begin is still copying the estimate of two pushes ago out of the buffer this step writes
+    if (c->est_guard > 0 && --c->est_guard == 0) HIPCHK(c, hipStreamWaitEvent(st, c->ev_est_done, 0));
     int rc = put_in(c, c->d_lr_t, lr_t, dev, B, 1, 3);
     if (rc) return rc;
     float* out = c->d_est[c->cur ^ 1];
@@ -1311,6 +1320,52 @@ int sr_clip_read_est(sr_ctx* c, int first, int n, float* est) {
     int rc = get_out(c, est, false, c->d_est[c->cur] + (size_t)first * img, n, 4, 3);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SR_OK;
+}
+
+int sr_clip_read_est_begin(sr_ctx* c, int first, int n, float* est) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    if (!c->clip_active) return fail(c, SR_ERR_STATE, "sr_clip_read_est_begin without sr_clip_begin");
+    if (!est) return fail(c, SR_ERR_ARG, "est is NULL");
+    if (first < 0 || n < 1 || first + n > c->clip_B) return fail(c, SR_ERR_ARG, "clips [%d, %d) outside the clip batch of %d", first, first + n, c->clip_B);
+    if (c->est_pending) return fail(c, SR_ERR_STATE, "sr_clip_read_est_begin: the previous read-back has not been ended");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->est_stream) {
+        bool ok = hipStreamCreateWithFlags(&c->est_stream, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&c->ev_est_src, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&c->ev_est_done, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            if (c->est_stream) (void)hipStreamDestroy(c->est_stream);
+            if (c->ev_est_src) (void)hipEventDestroy(c->ev_est_src);
+            if (c->ev_est_done) (void)hipEventDestroy(c->ev_est_done);
+            c->est_stream = nullptr;
+            c->ev_est_src = c->ev_est_done = nullptr;
+            return fail(c, SR_ERR_HIP, "estimate read-back: stream / event creation failed");
+        }
+    }
+    const size_t img = (size_t)c->h * c->w * 48;
+    const float* src = c->d_est[c->cur] + (size_t)first * img;
+    const size_t bytes = (size_t)n * 16 * c->h_in * c->w_in * 3 * 4;
+    if (c->pad) {   // crop on the step's stream into the dense staging tensor, copy that
+        LAUNCHCHK(c, "crop_copy", launch_crop_copy(src, c->d_io_hr, n, 4 * c->h_in, 4 * c->w_in, 3, 4 * c->h, 4 * c->w, c->stream));
+        src = c->d_io_hr;
+    }
+    HIPCHK(c, hipEventRecord(c->ev_est_src, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->est_stream, c->ev_est_src, 0));
+    HIPCHK(c, hipMemcpyAsync(est, src, bytes, hipMemcpyDeviceToHost, c->est_stream));
+    HIPCHK(c, hipEventRecord(c->ev_est_done, c->est_stream));
+    c->est_guard = 2;      // the next push reads this estimate, the one after it writes over it (or re-uses the staging tensor)
+    c->est_pending = true;
+    return SR_OK;
+}
+
+int sr_clip_read_est_end(sr_ctx* c) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    if (!c->est_pending) return fail(c, SR_ERR_STATE, "sr_clip_read_est_end without sr_clip_read_est_begin");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev_est_done));
+    c->est_pending = false;
     return SR_OK;
 }
 

@@ -82,6 +82,12 @@ struct sr_ctx {
     hipEvent_t ev_u8_ready[2] = {nullptr, nullptr}, ev_u8_done[2] = {nullptr, nullptr};
     int64_t u8_pushes = 0;
     bool u8_ready = false;   // every object of the path exists (set last; a failed first use frees what it made)
+    // float read-back of the newest estimate beside the following step (sr_clip_read_est_begin / _end): its own stream; est_guard
+    // counts the pushes that may still start before the copy has to be over (the second one overwrites the buffer it reads)
+    hipStream_t est_stream = nullptr;
+    hipEvent_t ev_est_src = nullptr, ev_est_done = nullptr;
+    int est_guard = 0;
+    bool est_pending = false;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;

@@ -44,6 +44,8 @@ SIGNATURES = {
     "sr_clip_push_u8": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "sr_u8_wait": (C.c_int, [_vp, C.c_int]),
     "sr_clip_read_est": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "sr_clip_read_est_begin": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "sr_clip_read_est_end": (C.c_int, [_vp]),
     "sr_host_alloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "sr_host_free": (C.c_int, [_vp]),
     "sr_fnet": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
@@ -305,6 +307,17 @@ class Context:
             raise ValueError(f"out: expected a contiguous float32 array of shape {shape}")
         _check(lib().sr_clip_read_est(self._h, int(first), int(n), _ptr(out)), self._h)
         return out
+
+    def clip_read_est_begin(self, out, first=0, n=1):
+        """Start the same read-back beside the next step (include/sr_hip.h sr_clip_read_est_begin).  out: a page-locked float32
+        array (PinnedArray.a) of shape (n,4h,4w,3); valid after clip_read_est_end().  The caller keeps `out` alive until then."""
+        shape = (int(n), 4 * self.h, 4 * self.w, 3)
+        if out.shape != shape or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError(f"out: expected a contiguous float32 array of shape {shape}")
+        _check(lib().sr_clip_read_est_begin(self._h, int(first), int(n), _ptr(out)), self._h)
+
+    def clip_read_est_end(self):
+        _check(lib().sr_clip_read_est_end(self._h), self._h)
 
     def fnet(self, lr_t, lr_tm1):
         B = int(np.shape(lr_t)[0])

@@ -93,3 +93,38 @@ def test_u8_output_equals_denormalized_float_output(sh, weights7, h, w, pad):
     ctx.u8_wait(0)
     np.testing.assert_array_equal(bufs[(T - 1) % 2], want[T - 1])
     ctx.close()
+
+
+@pytest.mark.parametrize("h,w,pad", [(24, 40, False), (20, 28, True)])
+def test_float_read_back_beside_the_following_steps(sh, weights7, h, w, pad):
+    """sr_clip_read_est_begin / _end: the float estimates of frame t, copied out while frames t + 1 and t + 2 are pushed, are
+    frame t's (the push after next waits on the device for the copy: it overwrites the buffer being read); the call-order
+    errors are SR_ERR_STATE."""
+    B, T = 3, 5
+    clip = np.stack([rn.synth_clip(20 + i, T, h, w) for i in range(B)], axis=1)
+    ctx = sh.Context(h, w, max_batch=B, pad=pad)
+    ctx.load_weights(weights7)
+    ctx.clip_begin(B)
+    want = [ctx.clip_push(clip[t]) for t in range(T)]
+    pin = sh.PinnedArray((2, 4 * h, 4 * w, 3), np.float32)
+    bufs = [np.zeros((B, 4 * h, 4 * w, 3), np.uint8) for _ in range(2)]
+    frames = [np.ascontiguousarray(clip[t]) for t in range(T)]
+    try:
+        with pytest.raises(RuntimeError, match="without sr_clip_read_est_begin"):
+            ctx.clip_read_est_end()
+        ctx.clip_begin(B)
+        for t in range(T):
+            ctx.clip_push_u8(frames[t].ctypes.data, bufs[t % 2].ctypes.data)
+            if t == 1:
+                pin.a[...] = -1.0
+                ctx.clip_read_est_begin(pin.a, first=1, n=2)       # clips 1, 2 of frame 1
+                with pytest.raises(RuntimeError, match="has not been ended"):
+                    ctx.clip_read_est_begin(pin.a, first=0, n=2)
+        ctx.clip_read_est_end()                                        # three more frames were pushed meanwhile
+        np.testing.assert_array_equal(pin.a, want[1][1:3])
+        ctx.u8_wait(0)
+        np.testing.assert_array_equal(ctx.clip_read_est(0, B), want[T - 1])
+    finally:
+        ctx.sync()
+        pin.close()
+        ctx.close()
