@@ -43,8 +43,8 @@ H_LR, W_LR, H_PAD = 180, 320, 184
 BATCH, FRAMES = 16, 10                # clips advanced in lock-step by one context; frames per clip
 FLOP_PER_LR_PX = 2210688.0            # 1,105,344 MAC per LR pixel per frame
 RES_CONV_FLOP_PER_LR_PX = 73728.0     # one 64->64 3x3 conv: 36,864 MAC per LR pixel
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}   # MI355X_MICROARCH.md dense peaks
-VERIFY_TOL = {"fp32": 1e-3, "bf16x3": 1e-3, "bf16": 0.15}
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0, "f16mx6": 2500.0}   # MI355X_MICROARCH.md dense peaks (f16 = bf16)
+VERIFY_TOL = {"fp32": 1e-3, "bf16x3": 1e-3, "f16mx6": 1e-3, "bf16": 0.15}
 
 
 def launch_ranks(args):
@@ -123,6 +123,7 @@ def kernel_profile(torch, ctx, lr_dev, steps):
 # into the traffic file as `trunk_kernel`).  bf16x3: the ReLU and the residual instantiation of conv_trunk.hip alternate,
 # the reported figure is their mean.
 TRUNK_KERNELS = {"bf16x3": ["trunk_conv_kernel<false, true, 0>", "trunk_conv_kernel<true, false, 0>"],
+                 "f16mx6": ["trunk6_conv_kernel<false, true, false, 0>", "trunk6_conv_kernel<true, false, false, 0>"],
                  "bf16": ["conv3x3_lds_kernel<1, 2, 2, true"], "fp32": ["conv3x3_lds_kernel<0, 2, 2, true"]}
 
 
@@ -284,7 +285,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16x3", choices=["fp32", "bf16", "bf16x3"])
+    ap.add_argument("--dtype", default="bf16x3", choices=["fp32", "bf16", "bf16x3", "f16mx6"])
     ap.add_argument("--clips-total", type=int, default=0,
                     help="total clips over all ranks (BASELINE configs[2]: 128), in lock-step batches of 16 per rank; "
                          "default 0 = 16 clips per GPU")
@@ -411,7 +412,7 @@ def main():
             gpu_frames = gpu_first_frames(torch, ctx, lr_devs[0], 4)
         ctx.close()
         others = {}
-        for d in ("fp32", "bf16", "bf16x3"):
+        for d in ("fp32", "bf16", "bf16x3", "f16mx6"):
             if d == args.dtype or world > 1:
                 continue
             c2 = make_ctx(d)

@@ -78,32 +78,54 @@ struct Rec6 {
     u32x4 lo6[2];
 };
 
-__device__ __forceinline__ void encode6(f32x16& V0, f32x16& V1, Rec6& o) {
-    float mx = 0.f, ml = 0.f;
+// encode6 in the three stages the kernel spreads over a tile's plane steps: the FP6 image of the values, then pair by pair the f16
+// hi parts (V becomes value - hi in place, ml its running maximum), then the FP6 image of what is left
+__device__ __forceinline__ void enc_x6(const f32x16& V0, const f32x16& V1, Rec6& o) {
+    float mx = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) mx = fmaxf(mx, fmaxf(fabsf(V0[i]), fabsf(V1[i])));
     const unsigned sx = mx_scale_bits(mx);
     const i32x6 cx = cvt_fp6_2x16(V0, V1, __builtin_bit_cast(float, sx));
     o.x6[0] = u32x4{(unsigned)cx[0], (unsigned)cx[1], (unsigned)cx[2], (unsigned)cx[3]};
     o.x6[1] = u32x4{(unsigned)cx[4], (unsigned)cx[5], sx >> 23, 0u};
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        f32x16& V = hh ? V1 : V0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            // f16 keeps 65504: what lies above goes to the FP6 parts instead of becoming inf
-            const float a = __builtin_amdgcn_fmed3f(V[2 * i], -65504.f, 65504.f), b = __builtin_amdgcn_fmed3f(V[2 * i + 1], -65504.f, 65504.f);
-            const f16x2 p = {(_Float16)a, (_Float16)b};
-            o.hi[2 * hh + (i >> 2)][i & 3] = __builtin_bit_cast(unsigned, p);
-            V[2 * i] -= (float)p[0];
-            V[2 * i + 1] -= (float)p[1];
-            ml = fmaxf(ml, fmaxf(fabsf(V[2 * i]), fabsf(V[2 * i + 1])));
-        }
-    }
+}
+template <int HH, int I>
+__device__ __forceinline__ void enc_hi_pair(f32x16& V, Rec6& o, float& ml) {
+    // f16 keeps 65504: what lies above goes to the FP6 parts instead of becoming inf
+    const float a = __builtin_amdgcn_fmed3f(V[2 * I], -65504.f, 65504.f), b = __builtin_amdgcn_fmed3f(V[2 * I + 1], -65504.f, 65504.f);
+    const f16x2 p = {(_Float16)a, (_Float16)b};
+    o.hi[2 * HH + (I >> 2)][I & 3] = __builtin_bit_cast(unsigned, p);
+    V[2 * I] -= (float)p[0];
+    V[2 * I + 1] -= (float)p[1];
+    ml = fmaxf(ml, fmaxf(fabsf(V[2 * I]), fabsf(V[2 * I + 1])));
+}
+__device__ __forceinline__ void enc_lo6(const f32x16& V0, const f32x16& V1, float ml, Rec6& o) {
     const unsigned sl = mx_scale_bits(ml);
     const i32x6 cl = cvt_fp6_2x16(V0, V1, __builtin_bit_cast(float, sl));
     o.lo6[0] = u32x4{(unsigned)cl[0], (unsigned)cl[1], (unsigned)cl[2], (unsigned)cl[3]};
     o.lo6[1] = u32x4{(unsigned)cl[4], (unsigned)cl[5], sl >> 23, 0u};
+}
+template <int N>
+__device__ __forceinline__ void enc_hi_pairs(f32x16& V0, f32x16& V1, Rec6& o, float& ml) {      // pair N of the 16: half N >> 3, pair N & 7
+    if constexpr (N < 8) enc_hi_pair<0, N>(V0, o, ml);
+    else enc_hi_pair<1, N - 8>(V1, o, ml);
+}
+template <int N>
+struct EncLoop {
+    static __device__ __forceinline__ void run(f32x16& V0, f32x16& V1, Rec6& o, float& ml) {
+        EncLoop<N - 1>::run(V0, V1, o, ml);
+        enc_hi_pairs<N - 1>(V0, V1, o, ml);
+    }
+};
+template <>
+struct EncLoop<0> {
+    static __device__ __forceinline__ void run(f32x16&, f32x16&, Rec6&, float&) {}
+};
+__device__ __forceinline__ void encode6(f32x16& V0, f32x16& V1, Rec6& o) {
+    float ml = 0.f;
+    enc_x6(V0, V1, o);
+    EncLoop<16>::run(V0, V1, o, ml);
+    enc_lo6(V0, V1, ml, o);
 }
 
 // the two f16 of a dword as floats, from a scalar: __builtin_bit_cast applied to a vector ELEMENT (bit_cast<f16x2>(v[k])) reads
@@ -111,19 +133,23 @@ __device__ __forceinline__ void encode6(f32x16& V0, f32x16& V1, Rec6& o) {
 __device__ __forceinline__ float h_even(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu)); }
 __device__ __forceinline__ float h_odd(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
 
-// V += hi + lo6 of a stored pixel (rh = its f16 record, rl = its lo6 block)
-__device__ __forceinline__ void decode_add6(f32x16& V0, f32x16& V1, const u32x4 (&rh)[4], const u32x4 (&rl)[2]) {
+// V += hi + lo6 of a stored pixel (rh = its f16 record, rl = its lo6 block), in two stages: the FP6 block as 32 f16, then pair by pair
+__device__ __forceinline__ f16x32 dec_lo(const u32x4 (&rl)[2]) {
     const i32x6 d = {(int)rl[0][0], (int)rl[0][1], (int)rl[0][2], (int)rl[0][3], (int)rl[1][0], (int)rl[1][1]};
     const float s = __builtin_bit_cast(float, (rl[1][2] & 0xFFu) << 23);
-    const f16x32 lo = cvt_f16_fp6_32(d, s);
+    return cvt_f16_fp6_32(d, s);
+}
+__device__ __forceinline__ void dec_add_pair(f32x16& V0, f32x16& V1, int i, const u32x4 (&rh)[4], const f16x32& lo) {
+    const unsigned p0 = rh[i >> 2][i & 3], p1 = rh[2 + (i >> 2)][i & 3];
+    V0[2 * i] += h_even(p0) + (float)lo[4 * i];
+    V1[2 * i] += h_even(p1) + (float)lo[4 * i + 1];
+    V0[2 * i + 1] += h_odd(p0) + (float)lo[4 * i + 2];
+    V1[2 * i + 1] += h_odd(p1) + (float)lo[4 * i + 3];
+}
+__device__ __forceinline__ void decode_add6(f32x16& V0, f32x16& V1, const u32x4 (&rh)[4], const u32x4 (&rl)[2]) {
+    const f16x32 lo = dec_lo(rl);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const unsigned p0 = rh[i >> 2][i & 3], p1 = rh[2 + (i >> 2)][i & 3];
-        V0[2 * i] += h_even(p0) + (float)lo[4 * i];
-        V1[2 * i] += h_even(p1) + (float)lo[4 * i + 1];
-        V0[2 * i + 1] += h_odd(p0) + (float)lo[4 * i + 2];
-        V1[2 * i + 1] += h_odd(p1) + (float)lo[4 * i + 3];
-    }
+    for (int i = 0; i < 8; ++i) dec_add_pair(V0, V1, i, rh, lo);
 }
 
 // the same 32 channels as two split-planar (conv_trunk.hip) plane records: what conv2d_transpose_1 reads
@@ -151,9 +177,12 @@ __device__ __forceinline__ void encode_split(const f32x16& V0, const f32x16& V1,
 //
 // Same skeleton as trunk_conv_kernel: persistent 512-thread workgroups, one channel half each with its 72 KiB of weights resident,
 // one DMA-staged 10 x 66 plane tile per step and one barrier per step.  The four plane steps of a tile issue 36 + 36 (f16 planes)
-// and 18 + 18 (FP6 planes) MFMAs.  The epilogue of tile n runs inside tile n + 1: residual loads at the top of step 0, the
-// residual add (or ReLU) under step 0 / 1, the conversions under step 2, the eight 16-byte stores under step 3.
-template <bool RELU, bool RES, bool OUT_SPLIT>
+// and 18 + 18 (FP6 planes) MFMAs.  The epilogue of tile n runs inside tile n + 1: its residual is loaded at the top of tile n's
+// last step, added (or the ReLU applied) under step 0, the conversions run under steps 1 and 2, and the eight 16-byte stores
+// leave two to four per step from step 1 on.
+// NOMEM (ablation builds of the micro-benchmark only, wrong results): 1 no tile DMA, 2 no MFMAs, 4 no epilogue loads / stores,
+// 8 no fragment reads from LDS, 16 no epilogue arithmetic
+template <bool RELU, bool RES, bool OUT_SPLIT, int NOMEM = 0>
 __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const wl = smem;
@@ -228,6 +257,7 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
     // byte offset of (plane pl, byte `add`) of the lane's pixel, or the dump area
     auto eoff = [&](unsigned pix, int pl, unsigned add) { return pix != ~0u ? pix + (unsigned)pl * plane_bytes + add : dump; };
     auto issue = [&](const Tile& q, int c, int buf) {
+        if (NOMEM & 1) return;
         const unsigned offc = q.off0 + (unsigned)c * plane_bytes;
         unsigned char* dst = abuf + buf * T6::A_BYTES;
 #pragma unroll
@@ -249,6 +279,12 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
     // residual of the finished tile's pixel: its f16 record (64 B) and lo6 block (32 B).  Inline asm: see trunk_conv_kernel
     u32x4 rh[4], rl[2];
     auto res_load = [&](unsigned pix) {
+        if (NOMEM & 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rh[k] = u32x4{0u, 0u, 0u, 0u};
+            rl[0] = rl[1] = u32x4{0u, 0u, 0u, 0u};
+            return;
+        }
         const unsigned oh = eoff(pix, half, 0u), ol = eoff(pix, 3, 32u * half);
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rh[0]) : "v"(oh), "s"(a.res) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(rh[1]) : "v"(oh), "s"(a.res) : "memory");
@@ -258,14 +294,20 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(rl[1]) : "v"(ol), "s"(a.res) : "memory");
     };
     auto res_landed = [&]() { asm volatile("" : "+v"(rh[0]), "+v"(rh[1]), "+v"(rh[2]), "+v"(rh[3]), "+v"(rl[0]), "+v"(rl[1])); };
-    auto store16 = [&](unsigned off, const u32x4& v) { *reinterpret_cast<u32x4*>(a.out + off) = v; };
+    auto store16 = [&](unsigned off, const u32x4& v) {
+        if (NOMEM & 4) asm volatile("" ::"v"(v));
+        else *reinterpret_cast<u32x4*>(a.out + off) = v;
+    };
 
     f32x16 acc[2], V0, V1;      // running tile; finished tile's pixel, lane half 0 / 1 channels
     unsigned done = ~0u;        // its pixel offset
     Rec6 rec;
     u32x4 osp[8];
+    f16x32 lodec;               // residual layers: the lo6 block of the finished tile's pixel, decoded (plane step 0)
+    float ml = 0.f;             // running max |value - hi| of the encoder (plane step 1)
 #pragma unroll
     for (int i = 0; i < 16; ++i) V0[i] = V1[i] = 0.f;
+    if (RES) res_load(~0u);     // the (empty) tile that drains under the first one
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();            // the bias
@@ -284,13 +326,18 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
         auto plane_step = [&](auto cc) {
             constexpr int C = decltype(cc)::value;
             constexpr int NM = C < 2 ? 4 : 2;       // MFMAs per tap
-            // the DMA of this step has landed; younger in the vmcnt queue: only the eight stores of step 3
-            if (C == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // The DMA of this step has landed; younger in the vmcnt queue: only the stores the previous step issued (x6: 2 in step 1,
+            // hi: 4 in step 2, lo6: 2 in step 3; split-planar output: 4 in step 2, 4 in step 3).  A step's stores so have the whole
+            // next step to complete, and never more than four are waited for at once: all eight in one step, waited for by the
+            // next, cost 25 us of a 64 us launch (tools/probe/trunk6_ablate.py).
+            constexpr int YOUNGER = (NOMEM & 4) ? 0 : OUT_SPLIT ? (C == 0 || C == 3 ? 4 : 0) : (C == 0 ? 2 : C == 1 ? 0 : C == 2 ? 2 : 4);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (RES && C == 0) res_load(done);      // before the DMA: older in the vmcnt queue, landed by the top of step 1
-            if (RES && C == 1) res_landed();
+            // the residual of the tile being computed, a whole step before its epilogue begins (step 0 of the next tile); before the
+            // DMA: older in the vmcnt queue, landed when that step has waited for its tile
+            if (RES && C == 3) res_load(cur.pix);
+            if (RES && C == 0) res_landed();
             if (C < 3) issue(cur, C + 1, (q + 1) & 1);
             else issue(nxt, 0, (q + 1) & 1);
             const unsigned char* at = abuf + (q & 1) * T6::A_BYTES;
@@ -308,12 +355,24 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
                 fb[s][0] = *reinterpret_cast<const u32x4*>(bw + (tap * 2 + 0) * 1024);
                 fb[s][1] = *reinterpret_cast<const u32x4*>(bw + (tap * 2 + 1) * 1024);
             };
-            load_tap(0, 0);
+            if (NOMEM & 8) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    fb[s2][0] = fb[s2][1] = u32x4{(unsigned)lane, 1u, 2u, 3u};
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) fa[s2][mb][0] = fa[s2][mb][1] = u32x4{(unsigned)lane, 5u, 6u, 7u};
+                }
+                asm volatile("" : "+v"(fb[0][0]), "+v"(fb[1][0]), "+v"(fa[0][0][0]), "+v"(fa[1][0][0]));
+            } else {
+                load_tap(0, 0);
+            }
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int s = tap & 1;
-                if (tap + 1 < 9) load_tap(tap + 1, s ^ 1);
-                if constexpr (C < 2) {
+                if (tap + 1 < 9 && !(NOMEM & 8)) load_tap(tap + 1, s ^ 1);
+                if constexpr (NOMEM & 2) {
+                    asm volatile("" ::"v"(fb[s][0]), "v"(fb[s][1]), "v"(fa[s][0][0]), "v"(fa[s][0][1]), "v"(fa[s][1][0]), "v"(fa[s][1][1]));
+                } else if constexpr (C < 2) {
                     const f16x8 w0 = __builtin_bit_cast(f16x8, fb[s][0]), w1 = __builtin_bit_cast(f16x8, fb[s][1]);
 #pragma unroll
                     for (int mb = 0; mb < 2; ++mb) {
@@ -330,8 +389,10 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
                         acc[mb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc[mb], 2, 2, 0, (int)fb[s][1][2], 0, (int)fa[s][mb][1][2]);
                     }
                 }
-                // the finished tile's epilogue, spread over the steps
-                if (RELU && C == 0 && tap >= 1) {
+                // The finished tile's epilogue, spread over the steps.  Step 0: ReLU, or the residual (one decode, then a pair of
+                // registers of each lane half per tap).  Step 1: the FP6 image under tap 0, two hi pairs under each other tap, the x6
+                // stores.  Step 2: the FP6 residue under tap 0, the hi stores.  Step 3: the lo6 stores.
+                if (RELU && C == 0 && tap >= 1 && !(NOMEM & 16)) {
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const int i = 2 * (tap - 1) + k;
@@ -339,27 +400,58 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
                         V1[i] = __builtin_amdgcn_fmed3f(V1[i], 0.f, __builtin_inff());
                     }
                 }
-                if (RES && C == 1 && tap == 1) decode_add6(V0, V1, rh, rl);
-                if (C == 2 && tap == 1) {
-                    if constexpr (OUT_SPLIT) encode_split(V0, V1, osp);
-                    else encode6(V0, V1, rec);
+                if constexpr (RES && C == 0 && !(NOMEM & 16)) {
+                    if (tap == 0) lodec = dec_lo(rl);
+                    else dec_add_pair(V0, V1, tap - 1, rh, lodec);
                 }
-                if (C == 3 && tap == 7) {
-                    if constexpr (OUT_SPLIT) {
-                        const unsigned o0 = eoff(done, 2 * half, 0u), o1 = eoff(done, 2 * half + 1, 0u);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            store16(o0 + 16 * k, osp[k]);
-                            store16(o1 + 16 * k, osp[4 + k]);
+                if constexpr (OUT_SPLIT) {
+                    if (C == 1 && tap == 1) encode_split(V0, V1, osp);
+                    if ((C == 2 || C == 3) && (tap == 2 || tap == 3)) {
+                        const unsigned o = eoff(done, 2 * half + (C - 2), 0u) + 32u * (tap - 2);
+                        store16(o, osp[4 * (C - 2) + 2 * (tap - 2)]);
+                        store16(o + 16, osp[4 * (C - 2) + 2 * (tap - 2) + 1]);
+                    }
+                } else if constexpr (NOMEM & 16) {
+                    const unsigned o = eoff(done, half, 0u);
+                    const u32x4 junk = u32x4{(unsigned)lane, 0u, 0u, 0u};
+                    if ((C == 1 && tap == 3) || (C == 2 && (tap == 2 || tap == 3)) || (C == 3 && tap == 2)) {
+                        store16(o, junk);
+                        store16(o + 16, junk);
+                    }
+                } else {
+                    if constexpr (C == 1) {
+                        if (tap == 0) {
+                            enc_x6(V0, V1, rec);
+                            ml = 0.f;
                         }
-                    } else {
-                        const unsigned oh = eoff(done, half, 0u), ox = eoff(done, 2, 32u * half), ol = eoff(done, 3, 32u * half);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) store16(oh + 16 * k, rec.hi[k]);
-                        store16(ox, rec.x6[0]);
-                        store16(ox + 16, rec.x6[1]);
-                        store16(ol, rec.lo6[0]);
-                        store16(ol + 16, rec.lo6[1]);
+                        if (tap == 1) { enc_hi_pairs<0>(V0, V1, rec, ml); enc_hi_pairs<1>(V0, V1, rec, ml); }
+                        if (tap == 2) { enc_hi_pairs<2>(V0, V1, rec, ml); enc_hi_pairs<3>(V0, V1, rec, ml); }
+                        if (tap == 3) { enc_hi_pairs<4>(V0, V1, rec, ml); enc_hi_pairs<5>(V0, V1, rec, ml); }
+                        if (tap == 4) { enc_hi_pairs<6>(V0, V1, rec, ml); enc_hi_pairs<7>(V0, V1, rec, ml); }
+                        if (tap == 5) { enc_hi_pairs<8>(V0, V1, rec, ml); enc_hi_pairs<9>(V0, V1, rec, ml); }
+                        if (tap == 6) { enc_hi_pairs<10>(V0, V1, rec, ml); enc_hi_pairs<11>(V0, V1, rec, ml); }
+                        if (tap == 7) { enc_hi_pairs<12>(V0, V1, rec, ml); enc_hi_pairs<13>(V0, V1, rec, ml); }
+                        if (tap == 8) { enc_hi_pairs<14>(V0, V1, rec, ml); enc_hi_pairs<15>(V0, V1, rec, ml); }
+                        if (tap == 3) {
+                            const unsigned ox = eoff(done, 2, 32u * half);
+                            store16(ox, rec.x6[0]);
+                            store16(ox + 16, rec.x6[1]);
+                        }
+                    }
+                    if constexpr (C == 2) {
+                        if (tap == 0) enc_lo6(V0, V1, ml, rec);
+                        if (tap == 2 || tap == 3) {
+                            const unsigned oh = eoff(done, half, 0u) + 32u * (tap - 2);
+                            store16(oh, rec.hi[2 * (tap - 2)]);
+                            store16(oh + 16, rec.hi[2 * (tap - 2) + 1]);
+                        }
+                    }
+                    if constexpr (C == 3) {
+                        if (tap == 2) {
+                            const unsigned ol = eoff(done, 3, 32u * half);
+                            store16(ol, rec.lo6[0]);
+                            store16(ol + 16, rec.lo6[1]);
+                        }
                     }
                 }
                 // behind each MFMA: the next tap's fragment reads and a share of the VALU / DMA instructions
@@ -402,8 +494,7 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
         cur = nxt;
     }
     // the last tile's epilogue has no MFMAs to hide under
-    if (RES) {
-        res_load(done);
+    if (RES) {      // its residual came with the last plane step
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         res_landed();
         decode_add6(V0, V1, rh, rl);
@@ -585,16 +676,16 @@ static int trunk6_num_cus() {
     return n;
 }
 
-template <bool RELU, bool RES, bool OUT_SPLIT>
+template <bool RELU, bool RES, bool OUT_SPLIT, int NOMEM = 0>
 static hipError_t launch_trunk6_t(const TrunkArgs& a, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trunk6_conv_kernel<RELU, RES, OUT_SPLIT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trunk6_conv_kernel<RELU, RES, OUT_SPLIT, NOMEM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T6::LDS);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((trunk6_conv_kernel<RELU, RES, OUT_SPLIT>), dim3(grid), dim3(512), T6::LDS, s, a);
+    hipLaunchKernelGGL((trunk6_conv_kernel<RELU, RES, OUT_SPLIT, NOMEM>), dim3(grid), dim3(512), T6::LDS, s, a);
     return hipGetLastError();
 }
 
@@ -613,6 +704,20 @@ hipError_t launch_trunk6_conv(TrunkArgs a, int out_split, hipStream_t s) {
     const int rounds = (per_xcd + npairs - 1) / npairs;
     npairs = (per_xcd + rounds - 1) / rounds;
     const int grid = 16 * npairs;
+    if (a.dbg && a.res && !out_split) {      // micro-benchmark ablations (tools/probe/trunk_ablate_b.py), residual layer
+        switch (a.dbg) {
+            case 1: return launch_trunk6_t<false, true, false, 1>(a, grid, s);
+            case 4: return launch_trunk6_t<false, true, false, 4>(a, grid, s);
+            case 5: return launch_trunk6_t<false, true, false, 5>(a, grid, s);
+            case 16: return launch_trunk6_t<false, true, false, 16>(a, grid, s);
+            case 21: return launch_trunk6_t<false, true, false, 21>(a, grid, s);      // MFMAs + fragment reads only
+            case 29: return launch_trunk6_t<false, true, false, 29>(a, grid, s);      // MFMAs only
+            case 23: return launch_trunk6_t<false, true, false, 23>(a, grid, s);      // fragment reads only
+            case 30: return launch_trunk6_t<false, true, false, 30>(a, grid, s);      // tile DMA only
+            case 27: return launch_trunk6_t<false, true, false, 27>(a, grid, s);      // epilogue memory only
+            default: return launch_trunk6_t<false, true, false, 31>(a, grid, s);      // the empty pipeline
+        }
+    }
     if (a.res) return out_split ? launch_trunk6_t<false, true, true>(a, grid, s) : launch_trunk6_t<false, true, false>(a, grid, s);
     return launch_trunk6_t<true, false, false>(a, grid, s);
 }

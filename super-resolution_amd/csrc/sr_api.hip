@@ -660,8 +660,8 @@ int run_srnet(sr_ctx* c, int B, float* d_out, bool split) {
                     LAUNCHCHK(c, "srnet.to_mx6", launch_split_to_mx6(sy, sx, nb, H, W, st));
                 }
                 for (int r = 0; r < 10; ++r) {
-                    if ((rc = trunk6(c->srnet[1 + 2 * r], sx, sy, nullptr, 1, 0, "srnet.res6"))) return rc;
-                    if ((rc = trunk6(c->srnet[2 + 2 * r], sy, r == 9 ? s_in : sx, sx, 0, r == 9, "srnet.res6"))) return rc;
+                    if ((rc = trunk6(c->srnet[1 + 2 * r], sx, sy, nullptr, 1, 0, "srnet.res"))) return rc;
+                    if ((rc = trunk6(c->srnet[2 + 2 * r], sy, r == 9 ? s_in : sx, sx, 0, r == 9, "srnet.res"))) return rc;
                 }
                 continue;
             }
@@ -1676,6 +1676,7 @@ int sr_bench_conv(int device, int dtype, int transposed, int B, int H, int W, in
             LAUNCHCHK(nullptr, "nhwc_to_mx6", launch_nhwc_to_mx6(d_f, bufs[k], B, H, W, nullptr));
         }
         TrunkArgs ta = {bufs[0], bufs[1], residual ? bufs[1] : nullptr, d_w, d_b, (unsigned)bytes, 0u, B, H, W, residual ? 0 : 1, 0, 0, 0};
+        if (const char* e = getenv("SR_CONV_DBG")) ta.dbg = atoi(e);      // ablations (conv_trunk6.hip), residual layer only
         hipEvent_t e0, e1;
         HIPCHK(nullptr, hipEventCreate(&e0));
         HIPCHK(nullptr, hipEventCreate(&e1));

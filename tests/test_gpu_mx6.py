@@ -137,3 +137,27 @@ def test_large_activations_do_not_overflow_f16(sh, weights7, split_always):
     out = ctx.step(lr_t, lr_tm1, est)[0]
     ctx.close()
     assert np.isfinite(out).all() and out.min() >= 0.0 and out.max() <= 1.0
+
+
+def test_training_updates_fall_back_to_bf16x3_until_the_next_commit(sh, weights7, split_always):
+    """sr_train_apply re-packs the bf16x3 buffers on the device, not the host-packed f16mx6 ones: after an update the ctx runs the
+    bf16x3 kernels (same numbers as a bf16x3 ctx that trained the same way); loading weights again brings conv_trunk6.hip back."""
+    h, w, B = 16, 24, 2
+    lr_t, lr_tm1, est = step_inputs(78, B, h, w)
+    hr = np.random.default_rng(6).random((B, 4 * h, 4 * w, 3), dtype=np.float32)
+    outs = {}
+    for dtype in ("bf16x3", "f16mx6"):
+        ctx = make_ctx(sh, weights7, h, w, B, dtype)
+        before = ctx.step(lr_t, lr_tm1, est)[0]
+        ctx.train_on_batch(lr_t, lr_tm1, est, hr, lr=2e-4)       # small: the trained net must stay well conditioned
+        after = ctx.step(lr_t, lr_tm1, est)[0]
+        trained = ctx.get_weights()
+        ctx.load_weights(trained)
+        again = ctx.step(lr_t, lr_tm1, est)[0]
+        ctx.close()
+        outs[dtype] = (before, after, again)
+    b3, b6 = outs["bf16x3"], outs["f16mx6"]
+    assert 0 < np.abs(b6[0] - b3[0]).max() <= 3e-4              # different kernels before training
+    np.testing.assert_array_equal(b6[1], b3[1])                   # the same kernels after it
+    assert np.abs(b3[1] - b3[0]).max() > 1e-4                     # and the update did change the weights
+    assert 0 < np.abs(b6[2] - b3[2]).max() <= 3e-4              # conv_trunk6.hip again, on the trained weights

@@ -32,7 +32,13 @@ step "train"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_train" -o out --output-format csv -- python3 "$R/tools/train_bench.py" --dtype bf16x3 --steps 5 >> "$OUT/log.txt" 2>&1 || exit 1
 step "gan"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_gan" -o out --output-format csv -- python3 "$R/tools/gan_bench.py" --iters 3 >> "$OUT/log.txt" 2>&1 || exit 1
+# 7. dtype f16mx6 (conv_trunk6.hip), one lane, whole-batch trunk launches
+step "f16mx6 one lane"
+export SR_LANES=1 SR_TRUNK_SUB=16
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_mx6" -o out --output-format csv -- python3 "$R/bench.py" --dtype f16mx6 --no-extras --steps 10 --warmup 3 >> "$OUT/log.txt" 2>&1 || exit 1
+unset SR_LANES SR_TRUNK_SUB
 cd "$R"
+python3 tools/pmc_summary.py stats "$OUT/stats_mx6" > "$OUT/${TAG}_bench_f16mx6_kernel_stats_1lane.csv"
 python3 tools/pmc_summary.py stats "$OUT/stats_default" > "$OUT/${TAG}_bench_bf16x3_kernel_stats.csv"
 python3 tools/pmc_summary.py durations "$OUT/stats_default" > "$OUT/${TAG}_bench_bf16x3_launch_durations.csv"
 python3 tools/pmc_summary.py stats "$OUT/stats_1lane" > "$OUT/${TAG}_bench_bf16x3_kernel_stats_1lane.csv"
