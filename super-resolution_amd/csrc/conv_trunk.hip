@@ -26,6 +26,7 @@
 // to the SOURCE address, the DMA writes LDS linearly): the 32 lanes of a ds_read_b128 fragment read then fall on 16
 // distinct 16-byte bank columns per 16-lane group -- conflict free without padding.
 #include "kernels.h"
+#include "mx6_format.h"
 
 #include <algorithm>
 #include <type_traits>
@@ -77,7 +78,9 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 // epilogue VALU (about 750 instructions per wave and tile) and the DMA address arithmetic took as long as the MFMAs.
 // Everything in a plane's body is branch free so that it stays one scheduling region: lanes outside the image load
 // from / store to a dump area behind the tensor instead of being masked off.
-template <bool RELU, bool RES, int NOMEM>
+// OUT6 (the head conv of a dtype f16mx6 ctx; ReLU layer): a.out takes the mx6 format of conv_trunk6.hip.  Not pipelined: swap of
+// the lane halves, ReLU, conversion and the eight stores follow each tile's last plane step (one launch in 21).
+template <bool RELU, bool RES, int NOMEM, bool OUT6 = false>
 __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const wl = smem;                 // resident weights of this workgroup's channel half
@@ -136,6 +139,7 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
         unsigned off0;      // offset of the halo origin of plane 0 (wraps for row -1 / column -1: only in-image units use it)
         unsigned okm;       // bit i: this lane's unit of DMA instruction i lies inside the image
         unsigned eoff[2];   // epilogue: offset of this lane's record of (M block, first plane of this half), or `dump`
+        unsigned pix6;      // OUT6: offset of pixel (M block h, column r) in half plane 0 of plane 0 of the mx6 output, or ~0u
     };
     // + one plane for the second plane of the half; a lane whose pixel lies outside the image stays in the dump area (M
     // block 1 of a tile that straddles the right edge is outside for lanes whose M block 0 pixel is inside)
@@ -160,6 +164,12 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
             const int x = x0 + 1 + mb * 32 + r;
             const bool ok = y < H && x < W;
             q.eoff[mb] = ok ? row + (unsigned)x * 64u : dump;
+        }
+        if constexpr (OUT6) {
+            const int x = x0 + 1 + 32 * h + r;
+            q.pix6 = (y < H && x < W) ? (unsigned)(b * 4) * plane_bytes + (unsigned)(y * W + x) * 32u : ~0u;
+        } else {
+            q.pix6 = 0u;
         }
         return q;
     };
@@ -258,12 +268,13 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
             constexpr int mbp = C >> 1, plp = C & 1;    // the piece of the finished tile that drains under this step
             // The DMA of this step has landed: vmcnt counts in issue order and the only younger operations are the two
             // stores of the previous step's epilogue piece (none in the ablation build without them).
-            if (NOMEM & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((NOMEM & 4) || (OUT6 && C != 0)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (OUT6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the eight stores behind the previous tile
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             __builtin_amdgcn_s_barrier();           // every wave's part landed; every wave is done reading the other buffer
             asm volatile("" ::: "memory");
             Piece& pc = pcs[C & 1];
-            {   // the next step's piece: C + 1 of the finished tile, or piece 0 of the tile being computed (finished by then)
+            if constexpr (!OUT6) {   // the next step's piece: C + 1 of the finished tile, or piece 0 of the tile being computed (finished by then)
                 constexpr int CN = (C + 1) & 3;
                 const unsigned base = C < 3 ? done.eoff[CN >> 1] : cur.eoff[0];
                 ep_load(pcs[(C + 1) & 1], base + ((CN & 1) ? estep(base) : 0u));   // before the DMA: older in the vmcnt queue
@@ -313,12 +324,14 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
                     }
                 }
                 // the epilogue piece, spread over the taps: pair k under tap 3 + k, the stores under tap 7
-                if (tap == 3) ep_landed(pc);
-                if (tap >= 3 && tap < 7) {
-                    const int k = tap - 3;
-                    ep_pair(pc, fin[mbp][8 * plp + 2 * k], fin[mbp][8 * plp + 2 * k + 1], k);
+                if constexpr (!OUT6) {
+                    if (tap == 3) ep_landed(pc);
+                    if (tap >= 3 && tap < 7) {
+                        const int k = tap - 3;
+                        ep_pair(pc, fin[mbp][8 * plp + 2 * k], fin[mbp][8 * plp + 2 * k + 1], k);
+                    }
+                    if (tap == 7) ep_store(pc);
                 }
-                if (tap == 7) ep_store(pc);
                 // one fragment read of the next tap and a few VALU / DMA instructions behind each MFMA
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
@@ -342,12 +355,38 @@ __global__ __launch_bounds__(512, 2) void trunk_conv_kernel(const TrunkArgs a) {
                 acc[1][i] += shp[1][i & 1][i >> 2];
             }
         }
+        if constexpr (OUT6) {      // this tile's epilogue, here and now, in the mx6 format (conv_trunk6.hip)
+            mx6::f32x16 V0, V1;
+            mx6::swap_halves(acc[0], acc[1], V0, V1);
+            if (RELU) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    V0[i] = __builtin_amdgcn_fmed3f(V0[i], 0.f, __builtin_inff());
+                    V1[i] = __builtin_amdgcn_fmed3f(V1[i], 0.f, __builtin_inff());
+                }
+            }
+            mx6::Rec6 rec;
+            mx6::encode6(V0, V1, rec);
+            const unsigned hplane = plane_bytes >> 1;      // the output has the input's geometry: half planes of H x W x 32 bytes
+            auto uoff = [&](int pl, int u) { return cur.pix6 != ~0u ? cur.pix6 + (unsigned)(2 * pl + (u >> 1)) * hplane + 16u * (u & 1) : dump + 16u * (u & 1); };
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(a.out + uoff(half, k)) = rec.hi[k];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                *reinterpret_cast<u32x4*>(a.out + uoff(2, 2 * half + k)) = rec.x6[k];
+                *reinterpret_cast<u32x4*>(a.out + uoff(3, 2 * half + k)) = rec.lo6[k];
+            }
+        }
         fin[0] = acc[0];
         fin[1] = acc[1];
         done = cur;
         if (!have_next) break;
         t = tn;
         cur = nxt;
+    }
+    if constexpr (OUT6) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
     }
     // the last tile's epilogue has no MFMAs to hide under
 #pragma unroll
@@ -661,16 +700,16 @@ static int trunk_num_cus() {
 
 size_t trunk_weight_bytes() { return (size_t)2 * TK::W_BYTES; }
 
-template <bool RELU, bool RES, int NOMEM>
+template <bool RELU, bool RES, int NOMEM, bool OUT6 = false>
 static hipError_t launch_trunk_t(const TrunkArgs& a, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trunk_conv_kernel<RELU, RES, NOMEM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trunk_conv_kernel<RELU, RES, NOMEM, OUT6>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, TK::LDS);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((trunk_conv_kernel<RELU, RES, NOMEM>), dim3(grid), dim3(512), TK::LDS, s, a);
+    hipLaunchKernelGGL((trunk_conv_kernel<RELU, RES, NOMEM, OUT6>), dim3(grid), dim3(512), TK::LDS, s, a);
     return hipGetLastError();
 }
 
@@ -740,6 +779,7 @@ hipError_t launch_trunk_conv(TrunkArgs a, hipStream_t s) {
             default: return launch_trunk_t<false, true, 7>(a, grid, s);
         }
     }
+    if (a.out_mx6) return a.res ? hipErrorInvalidValue : launch_trunk_t<true, false, 0, true>(a, grid, s);   // the head conv of an f16mx6 ctx
     return a.res ? launch_trunk_t<false, true, 0>(a, grid, s) : launch_trunk_t<true, false, 0>(a, grid, s);
 }
 

@@ -6,8 +6,14 @@
 // 2^-11 of the product, so 4 significant bits on them leave the sum at ~2^-15 relative: measured against the fp64 oracle in
 // tests/test_gpu_mx6.py (bar 1e-3 on [0, 1] pixels).
 //
-// Data layout ("mx6"): the same geometry as split-planar, [B][4 planes][H][W][64 B], so the tile DMA, the swizzle and every LDS
-// read address of conv_trunk.hip carry over unchanged.  Per pixel:
+// Data layout ("mx6"): [B][4 planes][2 halves][H][W][32 B] -- per pixel the same four planes of four 16-byte units as a
+// split-planar tensor, but units 2 h, 2 h + 1 of a plane (what lane half h reads, and what one lane writes of the FP6 planes) in a
+// half plane of their own.  What one lane loads or stores in the epilogue is 16 bytes: with 64-byte pixel records an instruction
+// touched 64 cache lines (one per lane) and the tag lookups of those 14 instructions per tile and wave cost as much as the MFMAs
+// (DESIGN.md 4.1d); with 32-byte records it touches 16, and a tile DMA instruction still 8 (16 pixels x 32 contiguous bytes from
+// each of two half planes; one plane per 16-byte unit makes the epilogue cheaper still and the DMA twice as slow).  The DMA
+// gathers a pixel's four units into the 64-byte LDS record of conv_trunk.hip (the source address of a global_load_lds lane is
+// free, the LDS side is linear), so the swizzle and every LDS read address carry over.  Per pixel:
 //   plane P = 0, 1: f16 hi parts of channels 32 P .. 32 P + 31; unit u = 2 h + ks (16 bytes) holds k-step ks of lane half h:
 //                   element e = channel 32 P + 16 ks + split_perm(h, e)
 //   plane 2 ("x6"): FP6 of the value itself; bytes [32 h, 32 h + 24) = the 32 channels of block h, element e (6 bits at bit 6 e)
@@ -21,6 +27,7 @@
 // order, v_cvt_scalef32_2xpk16_fp6_f32 interleaves the two halves' registers into one 24-byte FP6 block, and 8 consecutive
 // registers are one f16 unit.
 #include "kernels.h"
+#include "mx6_format.h"
 
 #include <algorithm>
 #include <cmath>
@@ -31,17 +38,14 @@
 namespace sr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x6 __attribute__((ext_vector_type(6)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 #define SR_AS1 __attribute__((address_space(1)))
 #define SR_AS3 __attribute__((address_space(3)))
+
+using namespace mx6;
 
 namespace {
 
@@ -58,122 +62,27 @@ struct T6 {
     static constexpr int LDS = BIAS_OFF + 128;              // 159,872 <= 163,840
 };
 
-// power of two s with m / s <= 7.5 (the largest E2M3 value); its exponent field is the E8M0 scale byte
-__device__ __forceinline__ unsigned mx_scale_bits(float m) {
-    unsigned b = (__builtin_bit_cast(unsigned, m * 0.13333334f) + 0x7FFFFFu) & 0x7F800000u;
-    return b < 0x0C800000u ? 0x0C800000u : b;      // >= 2^-102: m = 0 (or denormal) still divides
-}
-
-__device__ __forceinline__ i32x6 cvt_fp6_2x16(const f32x16& a, const f32x16& b, float scale) {
-    return __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(a, b, scale);      // element 2 i = a[i] / scale, 2 i + 1 = b[i] / scale
-}
-__device__ __forceinline__ f16x32 cvt_f16_fp6_32(const i32x6& d, float scale) {
-    return __builtin_amdgcn_cvt_scalef32_pk32_f16_fp6(d, scale);           // element e * scale
-}
-
-// the records of one pixel's 32 channels: V0 / V1 = the accumulator registers of lane half 0 / 1
-struct Rec6 {
-    u32x4 hi[4];    // f16 plane record: units 0, 1 from V0, units 2, 3 from V1
-    u32x4 x6[2];    // 24 bytes of FP6 + scale byte at byte 24
-    u32x4 lo6[2];
-};
-
-// encode6 in the three stages the kernel spreads over a tile's plane steps: the FP6 image of the values, then pair by pair the f16
-// hi parts (V becomes value - hi in place, ml its running maximum), then the FP6 image of what is left
-__device__ __forceinline__ void enc_x6(const f32x16& V0, const f32x16& V1, Rec6& o) {
-    float mx = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, fmaxf(fabsf(V0[i]), fabsf(V1[i])));
-    const unsigned sx = mx_scale_bits(mx);
-    const i32x6 cx = cvt_fp6_2x16(V0, V1, __builtin_bit_cast(float, sx));
-    o.x6[0] = u32x4{(unsigned)cx[0], (unsigned)cx[1], (unsigned)cx[2], (unsigned)cx[3]};
-    o.x6[1] = u32x4{(unsigned)cx[4], (unsigned)cx[5], sx >> 23, 0u};
-}
-template <int HH, int I>
-__device__ __forceinline__ void enc_hi_pair(f32x16& V, Rec6& o, float& ml) {
-    // f16 keeps 65504: what lies above goes to the FP6 parts instead of becoming inf
-    const float a = __builtin_amdgcn_fmed3f(V[2 * I], -65504.f, 65504.f), b = __builtin_amdgcn_fmed3f(V[2 * I + 1], -65504.f, 65504.f);
-    const f16x2 p = {(_Float16)a, (_Float16)b};
-    o.hi[2 * HH + (I >> 2)][I & 3] = __builtin_bit_cast(unsigned, p);
-    V[2 * I] -= (float)p[0];
-    V[2 * I + 1] -= (float)p[1];
-    ml = fmaxf(ml, fmaxf(fabsf(V[2 * I]), fabsf(V[2 * I + 1])));
-}
-__device__ __forceinline__ void enc_lo6(const f32x16& V0, const f32x16& V1, float ml, Rec6& o) {
-    const unsigned sl = mx_scale_bits(ml);
-    const i32x6 cl = cvt_fp6_2x16(V0, V1, __builtin_bit_cast(float, sl));
-    o.lo6[0] = u32x4{(unsigned)cl[0], (unsigned)cl[1], (unsigned)cl[2], (unsigned)cl[3]};
-    o.lo6[1] = u32x4{(unsigned)cl[4], (unsigned)cl[5], sl >> 23, 0u};
-}
-template <int N>
-__device__ __forceinline__ void enc_hi_pairs(f32x16& V0, f32x16& V1, Rec6& o, float& ml) {      // pair N of the 16: half N >> 3, pair N & 7
-    if constexpr (N < 8) enc_hi_pair<0, N>(V0, o, ml);
-    else enc_hi_pair<1, N - 8>(V1, o, ml);
-}
-template <int N>
-struct EncLoop {
-    static __device__ __forceinline__ void run(f32x16& V0, f32x16& V1, Rec6& o, float& ml) {
-        EncLoop<N - 1>::run(V0, V1, o, ml);
-        enc_hi_pairs<N - 1>(V0, V1, o, ml);
-    }
-};
-template <>
-struct EncLoop<0> {
-    static __device__ __forceinline__ void run(f32x16&, f32x16&, Rec6&, float&) {}
-};
-__device__ __forceinline__ void encode6(f32x16& V0, f32x16& V1, Rec6& o) {
-    float ml = 0.f;
-    enc_x6(V0, V1, o);
-    EncLoop<16>::run(V0, V1, o, ml);
-    enc_lo6(V0, V1, ml, o);
-}
-
-// the two f16 of a dword as floats, from a scalar: __builtin_bit_cast applied to a vector ELEMENT (bit_cast<f16x2>(v[k])) reads
-// element 0 whatever k is (hipcc, ROCm 7.2; tools/probe/mx6_dbg.py)
-__device__ __forceinline__ float h_even(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu)); }
-__device__ __forceinline__ float h_odd(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
-
-// V += hi + lo6 of a stored pixel (rh = its f16 record, rl = its lo6 block), in two stages: the FP6 block as 32 f16, then pair by pair
-__device__ __forceinline__ f16x32 dec_lo(const u32x4 (&rl)[2]) {
-    const i32x6 d = {(int)rl[0][0], (int)rl[0][1], (int)rl[0][2], (int)rl[0][3], (int)rl[1][0], (int)rl[1][1]};
-    const float s = __builtin_bit_cast(float, (rl[1][2] & 0xFFu) << 23);
-    return cvt_f16_fp6_32(d, s);
-}
-__device__ __forceinline__ void dec_add_pair(f32x16& V0, f32x16& V1, int i, const u32x4 (&rh)[4], const f16x32& lo) {
-    const unsigned p0 = rh[i >> 2][i & 3], p1 = rh[2 + (i >> 2)][i & 3];
-    V0[2 * i] += h_even(p0) + (float)lo[4 * i];
-    V1[2 * i] += h_even(p1) + (float)lo[4 * i + 1];
-    V0[2 * i + 1] += h_odd(p0) + (float)lo[4 * i + 2];
-    V1[2 * i + 1] += h_odd(p1) + (float)lo[4 * i + 3];
-}
-__device__ __forceinline__ void decode_add6(f32x16& V0, f32x16& V1, const u32x4 (&rh)[4], const u32x4 (&rl)[2]) {
-    const f16x32 lo = dec_lo(rl);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dec_add_pair(V0, V1, i, rh, lo);
-}
-
 // the same 32 channels as two split-planar (conv_trunk.hip) plane records: what conv2d_transpose_1 reads
-__device__ __forceinline__ void encode_split(const f32x16& V0, const f32x16& V1, u32x4 (&o)[8]) {
+template <int PL>
+__device__ __forceinline__ void encode_split_plane(const f32x16& V0, const f32x16& V1, u32x4 (&o)[4]) {      // plane PL of the two
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
+    for (int hh = 0; hh < 2; ++hh) {
+        const f32x16& V = hh ? V1 : V0;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const f32x16& V = hh ? V1 : V0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float a = V[8 * pl + 2 * k], b = V[8 * pl + 2 * k + 1];
-                const bf16x2 hv = {(__bf16)a, (__bf16)b};
-                const unsigned hu = __builtin_bit_cast(unsigned, hv);
-                const bf16x2 lv = {(__bf16)(a - __builtin_bit_cast(float, hu << 16)), (__bf16)(b - __builtin_bit_cast(float, hu & 0xFFFF0000u))};
-                o[4 * pl + 2 * hh][k] = hu;
-                o[4 * pl + 2 * hh + 1][k] = __builtin_bit_cast(unsigned, lv);
-            }
+        for (int k = 0; k < 4; ++k) {
+            const float a = V[8 * PL + 2 * k], b = V[8 * PL + 2 * k + 1];
+            const bf16x2 hv = {(__bf16)a, (__bf16)b};
+            const unsigned hu = __builtin_bit_cast(unsigned, hv);
+            const bf16x2 lv = {(__bf16)(a - __builtin_bit_cast(float, hu << 16)), (__bf16)(b - __builtin_bit_cast(float, hu & 0xFFFF0000u))};
+            o[2 * hh][k] = hu;
+            o[2 * hh + 1][k] = __builtin_bit_cast(unsigned, lv);
         }
+    }
 }
 
 }  // namespace
 
-// RELU: ReLU after the bias; RES: add a.res (mx6) after it.  OUT_SPLIT: write split-planar records (the last trunk layer).
+// RELU: ReLU after the bias; RES: add a.res (mx6) after it.
 //
 // Same skeleton as trunk_conv_kernel: persistent 512-thread workgroups, one channel half each with its 72 KiB of weights resident,
 // one DMA-staged 10 x 66 plane tile per step and one barrier per step.  The four plane steps of a tile issue 36 + 36 (f16 planes)
@@ -182,7 +91,10 @@ __device__ __forceinline__ void encode_split(const f32x16& V0, const f32x16& V1,
 // leave two to four per step from step 1 on.
 // NOMEM (ablation builds of the micro-benchmark only, wrong results): 1 no tile DMA, 2 no MFMAs, 4 no epilogue loads / stores,
 // 8 no fragment reads from LDS, 16 no epilogue arithmetic
-template <bool RELU, bool RES, bool OUT_SPLIT, int NOMEM = 0>
+// OUT_SPLIT (the trunk's last layer, a residual one): a.out takes split-planar records for conv2d_transpose_1.  Its epilogue is not
+// pipelined -- residual, conversion and stores follow each tile's last step -- which costs one launch in twenty a few microseconds
+// and keeps this variant's registers far from the limit (pipelined, with both output forms' state alive, it spilled).
+template <bool RELU, bool RES, int NOMEM = 0, bool OUT_SPLIT = false>
 __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const wl = smem;
@@ -204,7 +116,8 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
     int t = xcd * per_xcd + pair;
     if (t >= t_end) return;
 
-    const unsigned plane_bytes = (unsigned)(H * W * 64);
+    const unsigned hplane = (unsigned)(H * W * 32);          // one half plane (units 2 h, 2 h + 1 of a plane) of one image
+    const unsigned plane_bytes = 2u * hplane;
 
     {
         const unsigned char* wsrc = a.wpack + (size_t)half * T6::W_BYTES + lane * 16;
@@ -226,16 +139,17 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
         const int p = u >> 2, sl = (u & 3) ^ ((p >> 2) & 3);
         const int py = p / T6::HC, px = p - py * T6::HC;
         const bool exists = u < T6::NUNIT;
-        goff[i] = (py * W + px) * 64 + sl * 16;
+        goff[i] = (py * W + px) * 32 + (sl >> 1) * (int)hplane + (sl & 1) * 16;
         pyx[i] = exists ? (px | (py << 8)) : (1 << 28);
         asm volatile("" : "+v"(goff[i]), "+v"(pyx[i]));
     }
     const unsigned zoff = a.zero_off + (lane & 3) * 16;
     const unsigned dump = a.zero_off + 256 + lane * 32;          // lanes outside the image load / store here (64 bytes at most)
     struct Tile {
-        unsigned off0;      // offset of the halo origin of plane 0
+        unsigned off0;      // offset of the halo origin in unit plane 0 of plane 0
         unsigned okm;       // bit i: this lane's unit of DMA instruction i lies inside the image
-        unsigned pix;       // epilogue: offset of this lane's pixel (M block h, column r) in plane 0, or ~0u outside the image
+        unsigned pix;       // epilogue: offset of this lane's pixel (M block h, column r) in unit plane 0 of plane 0, or ~0u outside the image
+        unsigned pixs;      // OUT_SPLIT: its offset in plane 0 of the split-planar output
     };
     auto locate = [&](int tt) {
         Tile q;
@@ -243,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
         const int rem = tt - b * per_img;
         const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
         const int y0 = ty * T6::TH - 1, x0 = tx * T6::TWX - 1;
-        q.off0 = (unsigned)(b * 4) * plane_bytes + (unsigned)((y0 * W + x0) * 64);
+        q.off0 = (unsigned)(b * 4) * plane_bytes + (unsigned)((y0 * W + x0) * 32);
         q.okm = 0;
 #pragma unroll
         for (int i = 0; i < T6::PER_WAVE; ++i) {
@@ -251,11 +165,12 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
             q.okm |= ((gy < (unsigned)H) & (gx < (unsigned)W)) ? (1u << i) : 0u;
         }
         const int y = y0 + 1 + wave, x = x0 + 1 + 32 * h + r;
-        q.pix = (y < H && x < W) ? (unsigned)(b * 4) * plane_bytes + (unsigned)(y * W + x) * 64u : ~0u;
+        q.pix = (y < H && x < W) ? (unsigned)(b * 4) * plane_bytes + (unsigned)(y * W + x) * 32u : ~0u;
+        q.pixs = OUT_SPLIT ? (unsigned)(b * 4) * plane_bytes + (unsigned)(y * W + x) * 64u : 0u;
         return q;
     };
-    // byte offset of (plane pl, byte `add`) of the lane's pixel, or the dump area
-    auto eoff = [&](unsigned pix, int pl, unsigned add) { return pix != ~0u ? pix + (unsigned)pl * plane_bytes + add : dump; };
+    // byte offset of unit u of plane pl of the lane's pixel, or the dump area (two 16-byte slots per lane)
+    auto uoff = [&](unsigned pix, int pl, int u) { return pix != ~0u ? pix + (unsigned)(2 * pl + (u >> 1)) * hplane + 16u * (u & 1) : dump + 16u * (u & 1); };
     auto issue = [&](const Tile& q, int c, int buf) {
         if (NOMEM & 1) return;
         const unsigned offc = q.off0 + (unsigned)c * plane_bytes;
@@ -285,13 +200,16 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
             rl[0] = rl[1] = u32x4{0u, 0u, 0u, 0u};
             return;
         }
-        const unsigned oh = eoff(pix, half, 0u), ol = eoff(pix, 3, 32u * half);
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rh[0]) : "v"(oh), "s"(a.res) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(rh[1]) : "v"(oh), "s"(a.res) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(rh[2]) : "v"(oh), "s"(a.res) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:48" : "=v"(rh[3]) : "v"(oh), "s"(a.res) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rl[0]) : "v"(ol), "s"(a.res) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(rl[1]) : "v"(ol), "s"(a.res) : "memory");
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned o = uoff(pix, half, k);
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rh[k]) : "v"(o), "s"(a.res) : "memory");
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const unsigned o = uoff(pix, 3, 2 * half + k);
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rl[k]) : "v"(o), "s"(a.res) : "memory");
+        }
     };
     auto res_landed = [&]() { asm volatile("" : "+v"(rh[0]), "+v"(rh[1]), "+v"(rh[2]), "+v"(rh[3]), "+v"(rl[0]), "+v"(rl[1])); };
     auto store16 = [&](unsigned off, const u32x4& v) {
@@ -302,12 +220,11 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
     f32x16 acc[2], V0, V1;      // running tile; finished tile's pixel, lane half 0 / 1 channels
     unsigned done = ~0u;        // its pixel offset
     Rec6 rec;
-    u32x4 osp[8];
     f16x32 lodec;               // residual layers: the lo6 block of the finished tile's pixel, decoded (plane step 0)
     float ml = 0.f;             // running max |value - hi| of the encoder (plane step 1)
 #pragma unroll
     for (int i = 0; i < 16; ++i) V0[i] = V1[i] = 0.f;
-    if (RES) res_load(~0u);     // the (empty) tile that drains under the first one
+    if (RES && !OUT_SPLIT) res_load(~0u);     // the (empty) tile that drains under the first one
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();            // the bias
@@ -327,17 +244,17 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
             constexpr int C = decltype(cc)::value;
             constexpr int NM = C < 2 ? 4 : 2;       // MFMAs per tap
             // The DMA of this step has landed; younger in the vmcnt queue: only the stores the previous step issued (x6: 2 in step 1,
-            // hi: 4 in step 2, lo6: 2 in step 3; split-planar output: 4 in step 2, 4 in step 3).  A step's stores so have the whole
+            // hi: 4 in step 2, lo6: 2 in step 3).  A step's stores so have the whole
             // next step to complete, and never more than four are waited for at once: all eight in one step, waited for by the
             // next, cost 25 us of a 64 us launch (tools/probe/trunk6_ablate.py).
-            constexpr int YOUNGER = (NOMEM & 4) ? 0 : OUT_SPLIT ? (C == 0 || C == 3 ? 4 : 0) : (C == 0 ? 2 : C == 1 ? 0 : C == 2 ? 2 : 4);
+            constexpr int YOUNGER = (NOMEM & 4) ? 0 : OUT_SPLIT ? (C == 0 ? 8 : 0) : (C == 0 ? 2 : C == 1 ? 0 : C == 2 ? 2 : 4);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             // the residual of the tile being computed, a whole step before its epilogue begins (step 0 of the next tile); before the
             // DMA: older in the vmcnt queue, landed when that step has waited for its tile
-            if (RES && C == 3) res_load(cur.pix);
-            if (RES && C == 0) res_landed();
+            if (RES && !OUT_SPLIT && C == 3) res_load(cur.pix);
+            if (RES && !OUT_SPLIT && C == 0) res_landed();
             if (C < 3) issue(cur, C + 1, (q + 1) & 1);
             else issue(nxt, 0, (q + 1) & 1);
             const unsigned char* at = abuf + (q & 1) * T6::A_BYTES;
@@ -392,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
                 // The finished tile's epilogue, spread over the steps.  Step 0: ReLU, or the residual (one decode, then a pair of
                 // registers of each lane half per tap).  Step 1: the FP6 image under tap 0, two hi pairs under each other tap, the x6
                 // stores.  Step 2: the FP6 residue under tap 0, the hi stores.  Step 3: the lo6 stores.
-                if (RELU && C == 0 && tap >= 1 && !(NOMEM & 16)) {
+                if (RELU && !OUT_SPLIT && C == 0 && tap >= 1 && !(NOMEM & 16)) {
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const int i = 2 * (tap - 1) + k;
@@ -400,23 +317,16 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
                         V1[i] = __builtin_amdgcn_fmed3f(V1[i], 0.f, __builtin_inff());
                     }
                 }
-                if constexpr (RES && C == 0 && !(NOMEM & 16)) {
+                if constexpr (RES && !OUT_SPLIT && C == 0 && !(NOMEM & 16)) {
                     if (tap == 0) lodec = dec_lo(rl);
                     else dec_add_pair(V0, V1, tap - 1, rh, lodec);
                 }
                 if constexpr (OUT_SPLIT) {
-                    if (C == 1 && tap == 1) encode_split(V0, V1, osp);
-                    if ((C == 2 || C == 3) && (tap == 2 || tap == 3)) {
-                        const unsigned o = eoff(done, 2 * half + (C - 2), 0u) + 32u * (tap - 2);
-                        store16(o, osp[4 * (C - 2) + 2 * (tap - 2)]);
-                        store16(o + 16, osp[4 * (C - 2) + 2 * (tap - 2) + 1]);
-                    }
                 } else if constexpr (NOMEM & 16) {
-                    const unsigned o = eoff(done, half, 0u);
                     const u32x4 junk = u32x4{(unsigned)lane, 0u, 0u, 0u};
                     if ((C == 1 && tap == 3) || (C == 2 && (tap == 2 || tap == 3)) || (C == 3 && tap == 2)) {
-                        store16(o, junk);
-                        store16(o + 16, junk);
+                        store16(uoff(done, half, 0), junk);
+                        store16(uoff(done, half, 1), junk);
                     }
                 } else {
                     if constexpr (C == 1) {
@@ -433,24 +343,21 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
                         if (tap == 7) { enc_hi_pairs<12>(V0, V1, rec, ml); enc_hi_pairs<13>(V0, V1, rec, ml); }
                         if (tap == 8) { enc_hi_pairs<14>(V0, V1, rec, ml); enc_hi_pairs<15>(V0, V1, rec, ml); }
                         if (tap == 3) {
-                            const unsigned ox = eoff(done, 2, 32u * half);
-                            store16(ox, rec.x6[0]);
-                            store16(ox + 16, rec.x6[1]);
+                            store16(uoff(done, 2, 2 * half), rec.x6[0]);
+                            store16(uoff(done, 2, 2 * half + 1), rec.x6[1]);
                         }
                     }
                     if constexpr (C == 2) {
                         if (tap == 0) enc_lo6(V0, V1, ml, rec);
                         if (tap == 2 || tap == 3) {
-                            const unsigned oh = eoff(done, half, 0u) + 32u * (tap - 2);
-                            store16(oh, rec.hi[2 * (tap - 2)]);
-                            store16(oh + 16, rec.hi[2 * (tap - 2) + 1]);
+                            store16(uoff(done, half, 2 * (tap - 2)), rec.hi[2 * (tap - 2)]);
+                            store16(uoff(done, half, 2 * (tap - 2) + 1), rec.hi[2 * (tap - 2) + 1]);
                         }
                     }
                     if constexpr (C == 3) {
                         if (tap == 2) {
-                            const unsigned ol = eoff(done, 3, 32u * half);
-                            store16(ol, rec.lo6[0]);
-                            store16(ol + 16, rec.lo6[1]);
+                            store16(uoff(done, 3, 2 * half), rec.lo6[0]);
+                            store16(uoff(done, 3, 2 * half + 1), rec.lo6[1]);
                         }
                     }
                 }
@@ -479,19 +386,30 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
         plane_step(std::integral_constant<int, 2>{});
         plane_step(std::integral_constant<int, 3>{});
         // lane (r, h) takes all 32 channels of pixel (M block h, column r): V0 = lane half 0's registers, V1 = lane half 1's
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            // scalars first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index (hipcc, ROCm 7.2)
-            const float a0 = acc[0][i], a1 = acc[1][i];
-            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1), false, false);
-            const unsigned s0 = sw[0], s1 = sw[1];
-            V0[i] = __builtin_bit_cast(float, s0);
-            V1[i] = __builtin_bit_cast(float, s1);
-        }
+        swap_halves(acc[0], acc[1], V0, V1);
         done = cur.pix;
+        if constexpr (OUT_SPLIT) {      // this tile's epilogue, here and now
+            res_load(done);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the next tile's first DMA with it)
+            res_landed();
+            decode_add6(V0, V1, rh, rl);
+            const unsigned d0 = done != ~0u ? cur.pixs + (unsigned)(2 * half) * plane_bytes : dump;
+            const unsigned d1 = done != ~0u ? d0 + plane_bytes : dump;
+            u32x4 o[4];
+            encode_split_plane<0>(V0, V1, o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) store16(d0 + (done != ~0u ? 16u * k : 16u * (k & 1)), o[k]);
+            encode_split_plane<1>(V0, V1, o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) store16(d1 + (done != ~0u ? 16u * k : 16u * (k & 1)), o[k]);
+        }
         if (!have_next) break;
         t = tn;
         cur = nxt;
+    }
+    if constexpr (OUT_SPLIT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
     }
     // the last tile's epilogue has no MFMAs to hide under
     if (RES) {      // its residual came with the last plane step
@@ -506,71 +424,32 @@ __global__ __launch_bounds__(512, 2) void trunk6_conv_kernel(const TrunkArgs a) 
             V1[i] = __builtin_amdgcn_fmed3f(V1[i], 0.f, __builtin_inff());
         }
     }
-    if constexpr (OUT_SPLIT) {
-        encode_split(V0, V1, osp);
-        const unsigned o0 = eoff(done, 2 * half, 0u), o1 = eoff(done, 2 * half + 1, 0u);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            store16(o0 + 16 * k, osp[k]);
-            store16(o1 + 16 * k, osp[4 + k]);
-        }
-    } else {
+    {
         encode6(V0, V1, rec);
-        const unsigned oh = eoff(done, half, 0u), ox = eoff(done, 2, 32u * half), ol = eoff(done, 3, 32u * half);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) store16(oh + 16 * k, rec.hi[k]);
-        store16(ox, rec.x6[0]);
-        store16(ox + 16, rec.x6[1]);
-        store16(ol, rec.lo6[0]);
-        store16(ol + 16, rec.lo6[1]);
+        for (int k = 0; k < 4; ++k) store16(uoff(done, half, k), rec.hi[k]);
+        store16(uoff(done, 2, 2 * half), rec.x6[0]);
+        store16(uoff(done, 2, 2 * half + 1), rec.x6[1]);
+        store16(uoff(done, 3, 2 * half), rec.lo6[0]);
+        store16(uoff(done, 3, 2 * half + 1), rec.lo6[1]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// split-planar (bf16 hi / lo, conv_trunk.hip) -> mx6, one thread per (pixel, 32-channel block): the head conv's output
-__global__ __launch_bounds__(256) void split_to_mx6_kernel(const unsigned char* in, unsigned char* out, int B, int HW) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long n = (long)B * HW * 2;
-    if (idx >= n) return;
-    const int blk = (int)(idx & 1);
-    const long pb = idx >> 1;
-    const long b = pb / HW, p = pb - b * HW;
-    const size_t plane = (size_t)HW * 64;
-    const unsigned char* src = in + (size_t)b * 4 * plane + (size_t)p * 64;
-    f32x16 V0, V1;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const u32x4* rec = reinterpret_cast<const u32x4*>(src + (size_t)(2 * blk + ks) * plane);
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const u32x4 hv = rec[2 * hh], lv = rec[2 * hh + 1];
-            f32x16& V = hh ? V1 : V0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                V[8 * ks + 2 * k] = __builtin_bit_cast(float, hv[k] << 16) + __builtin_bit_cast(float, lv[k] << 16);
-                V[8 * ks + 2 * k + 1] = __builtin_bit_cast(float, hv[k] & 0xFFFF0000u) + __builtin_bit_cast(float, lv[k] & 0xFFFF0000u);
-            }
-        }
-    }
-    Rec6 o;
-    encode6(V0, V1, o);
-    unsigned char* dst = out + (size_t)b * 4 * plane + (size_t)p * 64;
-    u32x4* dh = reinterpret_cast<u32x4*>(dst + (size_t)blk * plane);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dh[k] = o.hi[k];
-    u32x4* dx = reinterpret_cast<u32x4*>(dst + 2 * plane + 32 * blk);
-    dx[0] = o.x6[0];
-    dx[1] = o.x6[1];
-    u32x4* dl = reinterpret_cast<u32x4*>(dst + 3 * plane + 32 * blk);
-    dl[0] = o.lo6[0];
-    dl[1] = o.lo6[1];
+// byte offset of unit u of plane `plane` of pixel p of image b in an mx6 tensor
+__device__ __forceinline__ size_t mx6_unit(long b, int HW, int plane, int u, long p) {
+    return (((size_t)b * 8 + 2 * plane + (u >> 1)) * HW + p) * 32 + 16 * (u & 1);
 }
 
-hipError_t launch_split_to_mx6(const void* in, void* out, int B, int H, int W, hipStream_t s) {
-    if (!in || !out || B < 1 || H < 1 || W < 1) return hipErrorInvalidValue;
-    const long n = (long)B * H * W * 2;
-    hipLaunchKernelGGL(split_to_mx6_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const unsigned char*)in, (unsigned char*)out, B, H * W);
-    return hipGetLastError();
+// the records of one pixel's 32-channel block blk to their unit planes
+__device__ __forceinline__ void mx6_store(unsigned char* out, long b, int HW, long p, int blk, const Rec6& o) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(out + mx6_unit(b, HW, blk, k, p)) = o.hi[k];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        *reinterpret_cast<u32x4*>(out + mx6_unit(b, HW, 2, 2 * blk + k, p)) = o.x6[k];
+        *reinterpret_cast<u32x4*>(out + mx6_unit(b, HW, 3, 2 * blk + k, p)) = o.lo6[k];
+    }
 }
 
 // ---- fp32 NHWC (64 channels) <-> mx6 / split-planar, for the per-op entry point sr_op_conv3x3_mx6 and its tests ----------------------
@@ -590,17 +469,7 @@ __global__ __launch_bounds__(256) void nhwc_to_mx6_kernel(const float* x, unsign
     }
     Rec6 o;
     encode6(V0, V1, o);
-    const size_t plane = (size_t)HW * 64;
-    unsigned char* dst = out + (size_t)b * 4 * plane + (size_t)p * 64;
-    u32x4* dh = reinterpret_cast<u32x4*>(dst + (size_t)blk * plane);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dh[k] = o.hi[k];
-    u32x4* dx = reinterpret_cast<u32x4*>(dst + 2 * plane + 32 * blk);
-    dx[0] = o.x6[0];
-    dx[1] = o.x6[1];
-    u32x4* dl = reinterpret_cast<u32x4*>(dst + 3 * plane + 32 * blk);
-    dl[0] = o.lo6[0];
-    dl[1] = o.lo6[1];
+    mx6_store(out, b, HW, p, blk, o);
 }
 
 // which = 0: the stored value hi + lo6; 1: the x6 plane alone (what the third MFMA term reads)
@@ -610,13 +479,11 @@ __global__ __launch_bounds__(256) void mx6_to_nhwc_kernel(const unsigned char* i
     const int blk = (int)(idx & 1);
     const long pb = idx >> 1;
     const long b = pb / HW, p = pb - b * HW;
-    const size_t plane = (size_t)HW * 64;
-    const unsigned char* src = in + (size_t)b * 4 * plane + (size_t)p * 64;
     u32x4 rh[4], rl[2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) rh[k] = which ? u32x4{0u, 0u, 0u, 0u} : reinterpret_cast<const u32x4*>(src + (size_t)blk * plane)[k];
-    rl[0] = reinterpret_cast<const u32x4*>(src + (which ? 2 : 3) * plane + 32 * blk)[0];
-    rl[1] = reinterpret_cast<const u32x4*>(src + (which ? 2 : 3) * plane + 32 * blk)[1];
+    for (int k = 0; k < 4; ++k) rh[k] = which ? u32x4{0u, 0u, 0u, 0u} : *reinterpret_cast<const u32x4*>(in + mx6_unit(b, HW, blk, k, p));
+#pragma unroll
+    for (int k = 0; k < 2; ++k) rl[k] = *reinterpret_cast<const u32x4*>(in + mx6_unit(b, HW, which ? 2 : 3, 2 * blk + k, p));
     f32x16 V0, V1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) V0[i] = V1[i] = 0.f;
@@ -676,25 +543,25 @@ static int trunk6_num_cus() {
     return n;
 }
 
-template <bool RELU, bool RES, bool OUT_SPLIT, int NOMEM = 0>
+template <bool RELU, bool RES, int NOMEM = 0, bool OUT_SPLIT = false>
 static hipError_t launch_trunk6_t(const TrunkArgs& a, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trunk6_conv_kernel<RELU, RES, OUT_SPLIT, NOMEM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trunk6_conv_kernel<RELU, RES, NOMEM, OUT_SPLIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T6::LDS);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((trunk6_conv_kernel<RELU, RES, OUT_SPLIT, NOMEM>), dim3(grid), dim3(512), T6::LDS, s, a);
+    hipLaunchKernelGGL((trunk6_conv_kernel<RELU, RES, NOMEM, OUT_SPLIT>), dim3(grid), dim3(512), T6::LDS, s, a);
     return hipGetLastError();
 }
 
-// a.in / a.res mx6, a.out mx6 or (out_split) split-planar; ReLU layers and residual layers like launch_trunk_conv
+// a.in / a.res mx6, a.out mx6 or (out_split, residual layer, NOT in place) split-planar; ReLU layers and residual layers like
+// launch_trunk_conv
 hipError_t launch_trunk6_conv(TrunkArgs a, int out_split, hipStream_t s) {
     if (a.B < 1 || a.H < 1 || a.W < 1 || !a.in || !a.out || !a.wpack || !a.bias) return hipErrorInvalidValue;
     if ((double)a.B * a.H * a.W * 256.0 + 4096.0 > 4294967295.0 || (double)a.zero_off + 4096.0 > 4294967295.0) return hipErrorInvalidValue;
     if ((a.relu != 0) == (a.res != nullptr)) return hipErrorInvalidValue;
-    if (out_split && !a.res) return hipErrorInvalidValue;      // only the trunk's last layer leaves the format
     a.tiles_x = (a.W + T6::TWX - 1) / T6::TWX;
     a.tiles_y = (a.H + T6::TH - 1) / T6::TH;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
@@ -704,22 +571,22 @@ hipError_t launch_trunk6_conv(TrunkArgs a, int out_split, hipStream_t s) {
     const int rounds = (per_xcd + npairs - 1) / npairs;
     npairs = (per_xcd + rounds - 1) / rounds;
     const int grid = 16 * npairs;
-    if (a.dbg && a.res && !out_split) {      // micro-benchmark ablations (tools/probe/trunk_ablate_b.py), residual layer
+    if (out_split) return a.res ? launch_trunk6_t<false, true, 0, true>(a, grid, s) : hipErrorInvalidValue;   // the trunk's last layer only
+    if (a.dbg && a.res) {      // micro-benchmark ablations (tools/probe/trunk_ablate_b.py), residual layer
         switch (a.dbg) {
-            case 1: return launch_trunk6_t<false, true, false, 1>(a, grid, s);
-            case 4: return launch_trunk6_t<false, true, false, 4>(a, grid, s);
-            case 5: return launch_trunk6_t<false, true, false, 5>(a, grid, s);
-            case 16: return launch_trunk6_t<false, true, false, 16>(a, grid, s);
-            case 21: return launch_trunk6_t<false, true, false, 21>(a, grid, s);      // MFMAs + fragment reads only
-            case 29: return launch_trunk6_t<false, true, false, 29>(a, grid, s);      // MFMAs only
-            case 23: return launch_trunk6_t<false, true, false, 23>(a, grid, s);      // fragment reads only
-            case 30: return launch_trunk6_t<false, true, false, 30>(a, grid, s);      // tile DMA only
-            case 27: return launch_trunk6_t<false, true, false, 27>(a, grid, s);      // epilogue memory only
-            default: return launch_trunk6_t<false, true, false, 31>(a, grid, s);      // the empty pipeline
+            case 1: return launch_trunk6_t<false, true, 1>(a, grid, s);
+            case 4: return launch_trunk6_t<false, true, 4>(a, grid, s);
+            case 5: return launch_trunk6_t<false, true, 5>(a, grid, s);
+            case 16: return launch_trunk6_t<false, true, 16>(a, grid, s);
+            case 21: return launch_trunk6_t<false, true, 21>(a, grid, s);      // MFMAs + fragment reads only
+            case 29: return launch_trunk6_t<false, true, 29>(a, grid, s);      // MFMAs only
+            case 23: return launch_trunk6_t<false, true, 23>(a, grid, s);      // fragment reads only
+            case 30: return launch_trunk6_t<false, true, 30>(a, grid, s);      // tile DMA only
+            case 27: return launch_trunk6_t<false, true, 27>(a, grid, s);      // epilogue memory only
+            default: return launch_trunk6_t<false, true, 31>(a, grid, s);      // the empty pipeline
         }
     }
-    if (a.res) return out_split ? launch_trunk6_t<false, true, true>(a, grid, s) : launch_trunk6_t<false, true, false>(a, grid, s);
-    return launch_trunk6_t<true, false, false>(a, grid, s);
+    return a.res ? launch_trunk6_t<false, true>(a, grid, s) : launch_trunk6_t<true, false>(a, grid, s);
 }
 
 // ---- host side: the packed weights of one 64 -> 64 layer, w = Keras kernel (3, 3, 64, 64) --------------------------------------------

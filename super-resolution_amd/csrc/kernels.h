@@ -86,14 +86,14 @@ struct TrunkArgs {
     int relu;                     // ReLU after the bias (before the residual)
     int tiles_x, tiles_y;         // set by the launcher
     int dbg;                      // ablation switches for the micro-benchmark (0 in production): 1 no tile DMA, 2 no MFMA loop, 4 no epilogue memory traffic
+    int out_mx6 = 0;              // launch_trunk_conv, ReLU layer: `out` takes the mx6 format of conv_trunk6.hip (the head conv of an f16mx6 ctx)
 };
 hipError_t launch_trunk_conv(TrunkArgs a, hipStream_t s);
 hipError_t launch_trunk_convT(TrunkArgs a, hipStream_t s);   // conv2d_transpose_1, split-planar in and out
 size_t trunk_weight_bytes();
-// the residual blocks' convs in f16 + MX FP6 arithmetic on "mx6" activations (conv_trunk6.hip): a.in / a.res / a.out mx6, or a.out
-// split-planar (out_split: the trunk's last layer); a.wpack = trunk6_pack_weights()
+// the residual blocks' convs in f16 + MX FP6 arithmetic on "mx6" activations (conv_trunk6.hip): a.in / a.res mx6, a.out mx6 or
+// (out_split: a residual layer, not in place) split-planar; a.wpack = trunk6_pack_weights()
 hipError_t launch_trunk6_conv(TrunkArgs a, int out_split, hipStream_t s);
-hipError_t launch_split_to_mx6(const void* in, void* out, int B, int H, int W, hipStream_t s);
 hipError_t launch_nhwc_to_mx6(const float* x, void* out, int B, int H, int W, hipStream_t s);                // x [B,H,W,64]
 hipError_t launch_mx6_to_nhwc(const void* in, float* y, int B, int H, int W, int which, hipStream_t s);      // which 0: hi + lo6, 1: x6
 hipError_t launch_split_to_nhwc(const void* in, float* y, int B, int H, int W, hipStream_t s);

@@ -642,8 +642,7 @@ int run_srnet(sr_ctx* c, int B, float* d_out, bool split) {
                 return SR_OK;
             };
             if (c->trunk_mx6 && c->mx6_valid) {
-                // head (bf16x3) -> sy, converted to mx6 in sx; the blocks ping-pong sx / sy in mx6; the last conv writes
-                // split-planar records again, into s_in (not in place: its output planes are other workgroups' residual planes)
+                // head (bf16x3 arithmetic) -> sx in mx6; the blocks ping-pong sx / sy in mx6
                 auto trunk6 = [&](const ConvLayer& L, const unsigned char* in, unsigned char* out, const unsigned char* res, int relu,
                                   int out_split, const char* name) -> int {
                     TrunkArgs ta = {in, out, res, (const unsigned char*)L.d_w6, L.d_bias, (unsigned)tail, 0u, nb, H, W, relu, 0, 0, 0};
@@ -653,14 +652,19 @@ int run_srnet(sr_ctx* c, int B, float* d_out, bool split) {
                     LAUNCHCHK(c, name, launch_trunk6_conv(ta, out_split, st));
                     return SR_OK;
                 };
-                int rc = trunk(c->srnet[0], s_in, sy, nullptr, 1, "srnet.head");
-                if (rc) return rc;
-                {
-                    ProfScope ps(c, "srnet.to_mx6", 0.0, (double)nb * H * W * 512.0);
-                    LAUNCHCHK(c, "srnet.to_mx6", launch_split_to_mx6(sy, sx, nb, H, W, st));
+                int rc;
+                {   // the head conv (bf16x3 arithmetic on the split-planar input) writes the format itself
+                    const ConvLayer& L = c->srnet[0];
+                    TrunkArgs ta = {s_in, sx, nullptr, (const unsigned char*)L.d_w2, L.d_bias, (unsigned)tail, 0u, nb, H, W, 1, 0, 0, 0, 1};
+                    const double px = (double)nb * H * W;
+                    ProfScope ps(c, "srnet.head", px * 9.0 * L.cin * L.cout * 2.0, px * 256.0 * 2 + (double)trunk_weight_bytes());
+                    if (tail + 4096 > 4294967295.0) return fail(c, SR_ERR_ARG, "srnet.head: tensor too large for 32-bit offsets");
+                    LAUNCHCHK(c, "srnet.head", launch_trunk_conv(ta, st));
                 }
                 for (int r = 0; r < 10; ++r) {
                     if ((rc = trunk6(c->srnet[1 + 2 * r], sx, sy, nullptr, 1, 0, "srnet.res"))) return rc;
+                    // x = x + conv(y) in place; the last one writes split-planar records into s_in for conv2d_transpose_1 (not in
+                    // place: its output planes are other workgroups' residual planes)
                     if ((rc = trunk6(c->srnet[2 + 2 * r], sy, r == 9 ? s_in : sx, sx, 0, r == 9, "srnet.res"))) return rc;
                 }
                 continue;
@@ -1540,7 +1544,7 @@ int sr_op_conv3x3_mx6(int device, int B, int H, int W, const float* x, const flo
     if (rc) return rc;
     if (!x || !out) return fail(nullptr, SR_ERR_ARG, "NULL tensor pointer");
     if (B < 1 || H < 1 || W < 1) return fail(nullptr, SR_ERR_ARG, "non-positive dimension");
-    if (mode < 0 || mode > 4) return fail(nullptr, SR_ERR_ARG, "mode must be 0..4");
+    if (mode < 0 || mode > 3) return fail(nullptr, SR_ERR_ARG, "mode must be 0..3");
     const size_t npix = (size_t)B * H * W, bytes = npix * 256;
     if ((double)bytes + 4096.0 > 4294967295.0) return fail(nullptr, SR_ERR_ARG, "tensor too large for 32-bit offsets");
     DevBufs d;
@@ -1556,11 +1560,6 @@ int sr_op_conv3x3_mx6(int device, int B, int H, int W, const float* x, const flo
     HIPCHK(nullptr, hipMemset(d_r + bytes, 0, 4096));
     HIPCHK(nullptr, hipMemcpy(d_f, x, npix * 64 * 4, hipMemcpyHostToDevice));
     LAUNCHCHK(nullptr, "nhwc_to_mx6", launch_nhwc_to_mx6(d_f, d_in, B, H, W, nullptr));
-    if (mode == 4) {     // the raw records (B x 4 planes x H x W x 64 bytes = as many bytes as `out` has)
-        HIPCHK(nullptr, hipDeviceSynchronize());
-        HIPCHK(nullptr, hipMemcpy(out, d_in, bytes, hipMemcpyDeviceToHost));
-        return SR_OK;
-    }
     if (mode >= 2) {     // the format alone: 2 = the stored value (hi + lo6), 3 = the x6 plane
         LAUNCHCHK(nullptr, "mx6_to_nhwc", launch_mx6_to_nhwc(d_in, d_f, B, H, W, mode - 2, nullptr));
         HIPCHK(nullptr, hipDeviceSynchronize());
@@ -1578,11 +1577,14 @@ int sr_op_conv3x3_mx6(int device, int B, int H, int W, const float* x, const flo
     trunk6_pack_weights(w, packed.data());
     HIPCHK(nullptr, hipMemcpy(d_w, packed.data(), packed.size(), hipMemcpyHostToDevice));
     HIPCHK(nullptr, hipMemcpy(d_b, bias, 64 * 4, hipMemcpyHostToDevice));
-    // a residual layer of the trunk updates x in place; the split-planar output cannot (conv_trunk6.hip)
+    // a residual layer of the trunk updates x in place
     TrunkArgs ta = {d_in, (res && mode == 0) ? d_r : d_o, res ? d_r : nullptr, d_w, d_b, (unsigned)bytes, 0u, B, H, W, relu, 0, 0, 0};
     LAUNCHCHK(nullptr, "trunk6", launch_trunk6_conv(ta, mode == 1, nullptr));
-    if (mode == 1) LAUNCHCHK(nullptr, "split_to_nhwc", launch_split_to_nhwc(ta.out, d_f, B, H, W, nullptr));
-    else LAUNCHCHK(nullptr, "mx6_to_nhwc", launch_mx6_to_nhwc(ta.out, d_f, B, H, W, 0, nullptr));
+    if (mode == 1) {     // the split-planar records conv2d_transpose_1 reads
+        LAUNCHCHK(nullptr, "split_to_nhwc", launch_split_to_nhwc(d_o, d_f, B, H, W, nullptr));
+    } else {
+        LAUNCHCHK(nullptr, "mx6_to_nhwc", launch_mx6_to_nhwc(ta.out, d_f, B, H, W, 0, nullptr));
+    }
     HIPCHK(nullptr, hipDeviceSynchronize());
     HIPCHK(nullptr, hipMemcpy(out, d_f, npix * 64 * 4, hipMemcpyDeviceToHost));
     return SR_OK;

@@ -47,7 +47,7 @@ def oracle_frames(weights7, bench_clips):
 
 
 @pytest.mark.parametrize("dtype,tol,psnr_tol,env", [("fp32", 1e-3, 0.01, {}), ("bf16x3", 1e-3, 0.01, {}), ("bf16", 0.15, 0.5, {}),
-                                                    ("bf16x3", 1e-3, 0.01, {"SR_TAIL": "0"})])
+                                                    ("bf16x3", 1e-3, 0.01, {"SR_TAIL": "0"}), ("f16mx6", 1e-3, 0.01, {})])
 def test_bench_configuration_every_frame(sh, weights7, bench_clips, oracle_frames, dtype, tol, psnr_tol, env):
     """env SR_TAIL=0: the x4 tail on the tap-major kernels (conv_mfma.hip) instead of conv_tail.hip's plane-major one."""
     hr = np.stack([rn.synth_clip(c, FRAMES, 4 * H, 4 * W, scale=4) for c in CHECKED], axis=1)   # common PSNR target
