@@ -4,7 +4,7 @@
 
 Same keys as the reference (root_dir, stage.{train,eval,run}, gpu, data.{low_res,high_res,channels,
 upscale,videos,rows,cols}, cnn.{model,pretrained_model}, eval.output_dir); extra optional keys:
-``dtype`` (fp32 | bf16x3 | bf16) and ``data.low_res_w`` / ``data.high_res_w`` for non-square tiles.
+``dtype`` (fp32 | bf16x3 | f16mx6 | bf16) and ``data.low_res_w`` / ``data.high_res_w`` for non-square tiles.
 For several GPUs launch one process per GPU:
     python -m torch.distributed.run --nproc-per-node N main.py --yaml_file X.yaml
 each rank evaluates a contiguous block of the clips (no collective: clips are independent).

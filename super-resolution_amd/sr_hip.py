@@ -445,6 +445,8 @@ class Discriminator:
     def __init__(self, H, W, max_batch=1, dtype="fp32", device=0):
         self.H, self.W, self.max_batch, self.device = int(H), int(W), int(max_batch), int(device)
         self.dtype = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+        if self.dtype == F16MX6:      # a generator dtype: these networks have no residual-block trunk, they run its bf16x3 kernels
+            self.dtype = BF16X3
         self._h = _vp()
         rc = lib().sr_disc_create(C.byref(self._h), device, H, W, max_batch, self.dtype)
         if rc:
@@ -559,6 +561,8 @@ class Vgg19:
     def __init__(self, H, W, max_batch=1, dtype="fp32", device=0):
         self.H, self.W, self.max_batch, self.device = int(H), int(W), int(max_batch), int(device)
         self.dtype = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+        if self.dtype == F16MX6:      # a generator dtype: these networks have no residual-block trunk, they run its bf16x3 kernels
+            self.dtype = BF16X3
         self._h = _vp()
         rc = lib().sr_vgg_create(C.byref(self._h), device, H, W, max_batch, self.dtype)
         if rc:

@@ -482,15 +482,16 @@ def test_bench_traffic_comes_from_the_newest_profile_and_never_from_another_kern
     sys.path.insert(0, root)
     import bench
     # the committed files: the newest one must resolve for the default dtype, and be the highest round on file
-    val, src, note = bench.pmc_traffic("bf16x3")
     rounds = sorted(int(f[1:f.index("_")]) for f in os.listdir(os.path.join(root, "profiles")) if f.endswith("_hbm_traffic.json") and f[1:f.index("_")].isdigit())
-    assert src == f"r{rounds[-1]}_hbm_traffic.json", (src, rounds)
-    assert val and 4e8 < val < 9e8, (val, note)          # 482 / 723 MB algorithmic on the two instantiations
-    d = json.load(open(os.path.join(root, "profiles", src)))
-    assert "trunk_kernel" in d and d["trunk_kernel"]["bf16x3"] == bench.TRUNK_KERNELS["bf16x3"]
+    for dtype in ("f16mx6", "bf16x3"):                  # the bench's default and the one it reports beside it
+        val, src, note = bench.pmc_traffic(dtype)
+        assert src == f"r{rounds[-1]}_hbm_traffic.json", (src, rounds)
+        assert val and 4e8 < val < 9e8, (dtype, val, note)          # 482 / 723 MB algorithmic on the two instantiations
+        d = json.load(open(os.path.join(root, "profiles", src)))
+        assert "trunk_kernel" in d and d["trunk_kernel"][dtype] == bench.TRUNK_KERNELS[dtype]
     # synthetic directory: r9 (without the kernels) shadows r3 (with them) -> None + note, not r3's number
     k = {"launches": 5, "fetch_bytes": 1, "write_bytes": 2, "hbm_bytes": 700}
-    json.dump({"kernels": {"trunk_conv_kernel<false, true, 0> @grid1": k, "trunk_conv_kernel<true, false, 0> @grid1": dict(k, hbm_bytes=500)}},
+    json.dump({"kernels": {"trunk_conv_kernel<false, true, 0, false> @grid1": k, "trunk_conv_kernel<true, false, 0, false> @grid1": dict(k, hbm_bytes=500)}},
               open(tmp_path / "r3_hbm_traffic.json", "w"))
     assert bench.pmc_traffic("bf16x3", str(tmp_path))[:2] == (600, "r3_hbm_traffic.json")
     json.dump({"kernels": {"some_other_kernel @grid1": k}}, open(tmp_path / "r9_hbm_traffic.json", "w"))
