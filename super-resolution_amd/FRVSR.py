@@ -311,9 +311,9 @@ class FrameRecurrentVideoSR(object):
                 if slots != Tmax and t > 0:
                     consume(t - 1)
                 # metric frames (every 10th, FRVSR.py:320): the float estimates of frame t leave the device beside step t + 1
-                # (sr_clip_read_est_begin) and are scored one iteration later, or after the loop
+                # (sr_clip_read_est_begin) and are scored two iterations later, or after the loop
                 est_f = None
-                if pending is not None:
+                if pending is not None and t >= pending[0] + 2:      # two steps later: the copy never holds the next push back
                     ctx.clip_read_est_end()
                     est_f, (tm, active_m, ms_m) = est_pin.a, pending
                     pending = None

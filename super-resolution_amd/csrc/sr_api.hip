@@ -875,6 +875,7 @@ int get_out(sr_ctx* c, float* dst, bool dst_dev, const float* d_src, int B, int 
         return SR_OK;
     }
     float* stage = (size_t)rows * cols * ch > (size_t)c->h_in * c->w_in * 3 ? c->d_io_hr : c->d_io_lr;
+    if (c->est_pending && !dst_dev && stage == c->d_io_hr) HIPCHK(c, hipStreamWaitEvent(st, c->ev_est_done, 0));   // sr_clip_read_est_begin is reading it
     float* ddst = dst_dev ? dst : stage;
     LAUNCHCHK(c, "crop_copy", launch_crop_copy(d_src, ddst, B, rows, cols, ch, scale * c->h, scale * c->w, st));
     if (!dst_dev) HIPCHK(c, hipMemcpyAsync(dst, stage, n, hipMemcpyDeviceToHost, st));
@@ -1359,7 +1360,9 @@ int sr_clip_read_est_begin(sr_ctx* c, int first, int n, float* est) {
     HIPCHK(c, hipStreamWaitEvent(c->est_stream, c->ev_est_src, 0));
     HIPCHK(c, hipMemcpyAsync(est, src, bytes, hipMemcpyDeviceToHost, c->est_stream));
     HIPCHK(c, hipEventRecord(c->ev_est_done, c->est_stream));
-    c->est_guard = 2;      // the next push reads this estimate, the one after it writes over it (or re-uses the staging tensor)
+    // the next push reads this estimate, the one after it writes over it; a padded ctx copies from the staging tensor, which
+    // no step touches (get_out waits for the copy before it re-uses that tensor)
+    c->est_guard = c->pad ? 0 : 2;
     c->est_pending = true;
     return SR_OK;
 }

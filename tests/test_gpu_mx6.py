@@ -161,3 +161,18 @@ def test_training_updates_fall_back_to_bf16x3_until_the_next_commit(sh, weights7
     np.testing.assert_array_equal(b6[1], b3[1])                   # the same kernels after it
     assert np.abs(b3[1] - b3[0]).max() > 1e-4                     # and the update did change the weights
     assert 0 < np.abs(b6[2] - b3[2]).max() <= 3e-4              # conv_trunk6.hip again, on the trained weights
+
+
+def test_error_does_not_grow_along_a_long_clip(sh, weights7, split_always):
+    """30 recurrent frames (three times the benched clip length): the estimate feeds back through the warp every frame, so a
+    format that drifted would show it here.  Per-frame max-abs against the oracle stays in the 1e-4 class."""
+    T = 30
+    clip = rn.synth_clip(5, T, 64, 64)[:, None]
+    want = rt.run_clip(weights7, clip)
+    ctx = make_ctx(sh, weights7, 64, 64, 1, "f16mx6")
+    ctx.clip_begin(1)
+    errs = [float(np.abs(ctx.clip_push(clip[t]) - want[t]).max()) for t in range(T)]
+    ctx.close()
+    print(f"\n[f16mx6, 30 frames] max-abs err: first 10 {max(errs[:10]):.2e}, middle {max(errs[10:20]):.2e}, last 10 {max(errs[20:]):.2e}")
+    assert max(errs) <= 3e-4
+    assert max(errs[20:]) <= 2.0 * max(errs[5:15]) + 1e-5
