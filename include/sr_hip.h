@@ -235,6 +235,19 @@ int sr_train_grads(sr_ctx* ctx, int B, const float* lr_t, const float* lr_tm1, c
 int sr_train_grads_dev(sr_ctx* ctx, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1,
                        const float* hr_t, float* d_grads, float* losses);
 int sr_train_read_grads(sr_ctx* ctx, float* host_out);
+/* ---- the data-parallel exchange on RCCL itself (SURVEY.md section 8 e; no counterpart in the reference, which trains on one
+ * device).  librccl.so is opened at run time by the first of these calls (SR_ERR_HIP with the loader's text if it is absent).
+ * sr_rccl_unique_id: rank 0 makes the 128-byte communicator id; the host program carries it to the other ranks (any channel;
+ * dp.py uses its torch.distributed group).  sr_rccl_comm_create: every rank, collectively, with its device current; *comm is
+ * an ncclComm_t.  sr_train_allreduce: ncclAllReduce(sum) in place on the flat gradient of the last sr_train_grads /
+ * sr_train_clips_grads -- d_grads, or the ctx's own buffer when NULL -- enqueued on the ctx stream: sr_train_apply(grad_scale =
+ * 1 / ranks) behind it needs no host synchronisation in between.  sr_rccl_allreduce_f32: the same for any device buffer and
+ * stream (the adversarial step's discriminator gradient, loss values). */
+int sr_rccl_unique_id(unsigned char* id128);
+int sr_rccl_comm_create(void** comm, const unsigned char* id128, int rank, int nranks, int device);
+int sr_rccl_comm_destroy(void* comm);
+int sr_rccl_allreduce_f32(void* comm, float* d_buf, int64_t n, void* hip_stream);
+int sr_train_allreduce(sr_ctx* ctx, void* comm, float* d_grads);
 int sr_train_apply(sr_ctx* ctx, const float* d_grads, float grad_scale, float lr, float beta1,
                    float beta2, float eps);
 int sr_train_on_batch(sr_ctx* ctx, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1,

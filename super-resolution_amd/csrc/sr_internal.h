@@ -225,6 +225,9 @@ void free_u8_path(sr_ctx* c);
 int run_step(sr_ctx* c, int B, const float* d_lr_t, const float* d_lr_tm1, const float* d_est_prev, float* d_est_out,
              float* d_lr_warp, float* d_hr_warp, bool warp_only);
 
+// sr_rccl.hip: in-place sum over the ranks of `comm` (an ncclComm_t), enqueued on st
+int rccl_allreduce_f32(sr_ctx* c, void* comm, float* d_buf, size_t n, hipStream_t st);
+
 // sr_train.hip
 void train_free(sr_ctx* c);
 int train_sync_host(sr_ctx* c);   // refresh ctx->tensors from the device master weights after training

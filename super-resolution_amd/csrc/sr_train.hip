@@ -621,6 +621,14 @@ int sr_train_read_grads(sr_ctx* c, float* host_out) {
     return SR_OK;
 }
 
+int sr_train_allreduce(sr_ctx* c, void* comm, float* d_grads) {
+    if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
+    if (!comm) return fail(c, SR_ERR_ARG, "comm is NULL");
+    if (!c->train) return fail(c, SR_ERR_STATE, "no gradients: call sr_train_grads first");
+    HIPCHK(c, hipSetDevice(c->device));
+    return rccl_allreduce_f32(c, comm, d_grads ? d_grads : c->train->d_grad, (size_t)c->train->nparams, c->stream);
+}
+
 int sr_train_apply(sr_ctx* c, const float* d_grads, float grad_scale, float lr, float beta1, float beta2, float eps) {
     if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
     if (!c->train) return fail(c, SR_ERR_STATE, "no gradients: call sr_train_grads first");

@@ -1,7 +1,9 @@
-"""Data-parallel plumbing of the training step: one process per GPU, torch.distributed over RCCL
-(backend "nccl" on ROCm) for the single exchange the path has -- the sum of the flat gradient vector
-(2,589,093 floats, 10.4 MB) over the ranks (SURVEY.md section 8 e).  PyTorch is plumbing only: the
-gradient is produced and consumed by libsr_hip.so; the torch tensor is the buffer RCCL reduces.
+"""Data-parallel plumbing of the training step: one process per GPU and the single exchange the path has -- the sum of the
+flat gradient vector (2,589,093 floats, 10.4 MB) over the ranks (SURVEY.md section 8 e).  Under the "nccl" backend (RCCL on
+ROCm) the exchange is libsr_hip's own ncclAllReduce on its own communicator (include/sr_hip.h sr_rccl_*, sr_train_allreduce),
+enqueued on the library's stream in front of the Adam step; torch.distributed only launches the ranks, carries the 128-byte
+communicator id from rank 0 and broadcasts the initial weights.  SR_DP_DIRECT=0 sends the exchange through torch's all_reduce
+instead, and the "gloo" backend (CPU rehearsal of several ranks on one GPU) stages it through the host.
 
 The job's batch is the union of the ranks' equal-sized batches; each rank's gradient is that of the mean
 loss over ITS batch, so the gradient of the mean over the global batch is the sum over ranks divided by
@@ -33,6 +35,41 @@ def init_if_needed(backend=None):
         os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group(backend or os.environ.get('SR_DIST_BACKEND', 'nccl'), rank=rank, world_size=n)
     return n
+
+
+_comm = None
+
+
+def direct():
+    """Is the exchange on libsr_hip's own RCCL communicator?"""
+    import torch.distributed as dist
+    return (dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl'
+            and os.environ.get('SR_DP_DIRECT', '1') != '0')
+
+
+def comm(device):
+    """The process's RcclComm over all ranks, made on first use (collective: every rank calls it at the same point)."""
+    global _comm
+    if _comm is None:
+        import torch
+        import torch.distributed as dist
+        import sr_hip
+        rank, n = dist.get_rank(), dist.get_world_size()
+        ident = sr_hip.RcclComm.unique_id() if rank == 0 else bytes(128)
+        box = torch.tensor(list(ident), dtype=torch.uint8, device=f'cuda:{device}')
+        dist.broadcast(box, src=0)
+        _comm = sr_hip.RcclComm(bytes(box.cpu().tolist()), rank, n, device)
+        import atexit
+        atexit.register(shutdown)
+    return _comm
+
+
+def shutdown():
+    """Destroy the library's communicator (before torch.distributed.destroy_process_group)."""
+    global _comm
+    if _comm is not None:
+        _comm.close()
+        _comm = None
 
 
 def mean_over_ranks_(tensor):
@@ -69,17 +106,33 @@ class GradBuffer:
 
     def __init__(self, n, device, n_losses=3):
         import torch
+        self.device = int(device)
         self.t = torch.empty(int(n), dtype=torch.float32, device=f'cuda:{device}')
         self.losses = torch.empty(int(n_losses), dtype=torch.float32, device=f'cuda:{device}')
+        self.grad_scale = 1.0       # what the Adam step multiplies the reduced buffer by
 
     def ptr(self):
         return self.t.data_ptr()
 
-    def reduce(self, losses):
-        """Sum-average gradient and losses over the ranks; returns the averaged losses as floats."""
+    def reduce(self, losses, ctx=None):
+        """Gradient and losses over the ranks; returns the averaged losses as floats.  On the direct path the buffer is left
+        holding the SUM and grad_scale = 1 / ranks goes to the Adam step; on the torch paths the buffer holds the mean.
+        ctx: the sr_hip.Context whose gradient (all of this buffer) it is -- the all-reduce then runs on that ctx's stream."""
         import torch
         import torch.distributed as dist
         self.losses.copy_(torch.tensor(losses, dtype=torch.float32))
+        if direct():
+            # the ctx stream is a blocking stream: its work and the null stream's (torch's copies, the second all-reduce)
+            # are ordered as issued, and nothing here waits on the host until the losses are read back
+            c = comm(self.device)
+            if ctx is not None:
+                ctx.train_allreduce(c, self.ptr())
+            else:
+                c.allreduce_f32(self.ptr(), self.t.numel())
+            c.allreduce_f32(self.losses.data_ptr(), self.losses.numel())
+            self.grad_scale = 1.0 / c.nranks
+            return [float(v) / c.nranks for v in self.losses.cpu()]
+        self.grad_scale = 1.0
         if dist.is_initialized() and dist.get_backend() == 'gloo':
             # rehearsal without RCCL (several ranks on one GPU, CPU-only collectives): stage through the host
             for t in (self.t, self.losses):

@@ -357,8 +357,8 @@ class GeneratorModel(_CoreModel):
             if getattr(self, '_gbuf', None) is None:
                 self._gbuf = dp.GradBuffer(ctx.param_count(), self.core.device)
             losses = ctx.train_grads(lr_t, lr_tm1, est_tm1, hr_t, d_grads=self._gbuf.ptr())
-            losses = self._gbuf.reduce(losses)
-            ctx.train_apply(d_grads=self._gbuf.ptr(), lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon)
+            losses = self._gbuf.reduce(losses, ctx)
+            ctx.train_apply(d_grads=self._gbuf.ptr(), grad_scale=self._gbuf.grad_scale, lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon)
         else:
             losses = ctx.train_grads(lr_t, lr_tm1, est_tm1, hr_t)
             ctx.train_apply(lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon)
@@ -382,8 +382,8 @@ class GeneratorModel(_CoreModel):
             dp.init_if_needed()
             if getattr(self, '_gbuf', None) is None:
                 self._gbuf = dp.GradBuffer(ctx.param_count(), self.core.device)
-            losses = self._gbuf.reduce(ctx.train_clips_grads(hr_clips, d_grads=self._gbuf.ptr()))
-            ctx.train_apply(d_grads=self._gbuf.ptr(), lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon)
+            losses = self._gbuf.reduce(ctx.train_clips_grads(hr_clips, d_grads=self._gbuf.ptr()), ctx)
+            ctx.train_apply(d_grads=self._gbuf.ptr(), grad_scale=self._gbuf.grad_scale, lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon)
         else:
             losses = ctx.train_clips_grads(hr_clips)
             ctx.train_apply(lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon)
@@ -564,7 +564,7 @@ class DiscriminatorModel(_Model):
             loss = d.train_grads(imgs, labels)
             d.read_grads(d_out=self._gbuf.ptr())
             loss = self._gbuf.reduce([loss, 0.0, 0.0])[0]
-            d.apply(opt.iterations, d_grads=self._gbuf.ptr(), **kw)
+            d.apply(opt.iterations, d_grads=self._gbuf.ptr(), grad_scale=self._gbuf.grad_scale, **kw)
         else:
             loss = d.train_grads(imgs, labels)
             d.apply(opt.iterations, **kw)
@@ -680,7 +680,8 @@ class TecoGANModel(_Model):
                 self._gbuf = dp.GradBuffer(ng + nd, self.gen.core.device, n_losses=13)
             sr_hip.tecogan_read_grads_dev(ctx, d, self._gbuf.ptr(), self._gbuf.ptr() + 4 * ng)
             losses = self._gbuf.reduce(losses)
-            sr_hip.tecogan_apply(ctx, d, opt.iterations, d_gen_grads=self._gbuf.ptr(), d_disc_grads=self._gbuf.ptr() + 4 * ng, **kw)
+            sr_hip.tecogan_apply(ctx, d, opt.iterations, d_gen_grads=self._gbuf.ptr(), d_disc_grads=self._gbuf.ptr() + 4 * ng,
+                                 grad_scale=self._gbuf.grad_scale, **kw)
         else:
             sr_hip.tecogan_apply(ctx, d, opt.iterations, **kw)
         self.gen.core._dirty = True

@@ -69,6 +69,11 @@ SIGNATURES = {
     "sr_train_grads_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _f32p]),
     "sr_train_read_grads": (C.c_int, [_vp, _vp]),
     "sr_train_apply": (C.c_int, [_vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "sr_rccl_unique_id": (C.c_int, [_vp]),
+    "sr_rccl_comm_create": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, C.c_int, C.c_int]),
+    "sr_rccl_comm_destroy": (C.c_int, [_vp]),
+    "sr_rccl_allreduce_f32": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "sr_train_allreduce": (C.c_int, [_vp, _vp, _vp]),
     "sr_train_on_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_float, _f32p]),
     "sr_train_iterations": (C.c_int64, [_vp]),
     "sr_train_clips_grads": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _f32p]),
@@ -361,6 +366,10 @@ class Context:
         g = np.empty(self.param_count(), np.float32)
         _check(lib().sr_train_read_grads(self._h, _ptr(g)), self._h)
         return list(losses), g
+
+    def train_allreduce(self, comm, d_grads=None):
+        """Sum of the flat gradient over the ranks of `comm` (RcclComm), in place, on this ctx's stream (include/sr_hip.h)."""
+        _check(lib().sr_train_allreduce(self._h, comm.handle, _vp(d_grads) if d_grads else None), self._h)
 
     def train_apply(self, d_grads=None, grad_scale=1.0, lr=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
         _check(lib().sr_train_apply(self._h, _vp(d_grads) if d_grads else None, grad_scale, lr, beta_1, beta_2, epsilon), self._h)
@@ -663,6 +672,34 @@ def tecogan_iteration(ctx, disc, batch, loss_weights, t0, lr=5e-5, beta_1=0.9, b
 def tecogan_read_grads_dev(ctx, disc, d_gen_out=None, d_disc_out=None):
     _check(lib().sr_tecogan_read_grads_dev(ctx._h, disc._h, _vp(d_gen_out) if d_gen_out else None, _vp(d_disc_out) if d_disc_out else None),
            ctx._h)
+
+
+class RcclComm(object):
+    """An RCCL communicator owned by libsr_hip (include/sr_hip.h sr_rccl_*).  id_bytes: the 128 bytes rank 0 got from
+    RcclComm.unique_id(), carried to every rank by the caller."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * 128)()
+        _check(lib().sr_rccl_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, id_bytes, rank, nranks, device=0):
+        if len(id_bytes) != 128:
+            raise ValueError("the communicator id is 128 bytes")
+        self.rank, self.nranks = int(rank), int(nranks)
+        h = _vp()
+        buf = (C.c_ubyte * 128).from_buffer_copy(id_bytes)
+        _check(lib().sr_rccl_comm_create(C.byref(h), buf, self.rank, self.nranks, int(device)))
+        self.handle = h
+
+    def allreduce_f32(self, d_ptr, n, stream=None):
+        _check(lib().sr_rccl_allreduce_f32(self.handle, _vp(d_ptr), int(n), _vp(stream) if stream else None))
+
+    def close(self):
+        if self.handle:
+            lib().sr_rccl_comm_destroy(self.handle)
+            self.handle = None
 
 
 # ---------------------------------------------------------------- single ops

@@ -101,10 +101,11 @@ def test_two_ranks_train_like_one_process_on_the_whole_batch(weights7):
             np.testing.assert_array_equal(x, y)                                        # the ranks stay in lock step exactly
 
 
-def _rccl_worker(port, out):
-    """ONE rank on backend nccl (= RCCL): the gradient goes through the same all-reduce a multi-GPU job runs."""
+def _rccl_worker(port, out, direct):
+    """ONE rank on backend nccl (= RCCL): the gradient goes through the same all-reduce a multi-GPU job runs -- the library's own
+    ncclAllReduce on its own communicator (direct), or torch.distributed's (SR_DP_DIRECT=0)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-                      SR_DP_FORCE="1", SR_DIST_BACKEND="nccl")
+                      SR_DP_FORCE="1", SR_DIST_BACKEND="nccl", SR_DP_DIRECT="1" if direct else "0")
     for p in (ROOT, os.path.join(ROOT, "super-resolution_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -121,6 +122,13 @@ def _rccl_worker(port, out):
     a, b, c, hr = _batch(2, 16, 16)
     losses = m.train_on_batch([a, b, c], [hr, a])
     assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    assert dp.direct() == direct and (dp._comm is not None) == direct
+    if direct:
+        # the communicator on a plain device buffer: a one-rank sum leaves it as it was
+        import torch
+        t = torch.arange(1000, dtype=torch.float32, device="cuda:0")
+        dp._comm.allreduce_f32(t.data_ptr(), t.numel())
+        assert dp._comm.nranks == 1 and np.array_equal(t.cpu().numpy(), np.arange(1000, dtype=np.float32))
     w_gen = [x.copy() for x in m.get_weights()]
     # the adversarial models use the same path: discriminator step and combined step through RCCL
     d = Discriminator((64, 64, 3), device=0).build()
@@ -135,6 +143,7 @@ def _rccl_worker(port, out):
     gl = g.train_on_batch([a, b, c] + imgs[:5], [hr, np.ones(2, np.float32)] + feats + [hr] * 4 + [hr[::-1].copy(), a])
     out.put((losses, w_gen, dl, gl, [x.copy() for x in m.get_weights()], [x.copy() for x in d.get_weights()], opt.iterations))
     dist.barrier()
+    dp.shutdown()
     dist.destroy_process_group()
 
 
@@ -148,14 +157,16 @@ def _gan_images():
     return [rng.random((2, 64, 64, 3), dtype=np.float32) for _ in range(9)]
 
 
-def test_one_rank_on_rccl_equals_the_plain_process(weights7):
+@pytest.mark.parametrize("direct", [True, False], ids=["library_rccl", "torch_all_reduce"])
+def test_one_rank_on_rccl_equals_the_plain_process(weights7, direct):
     """The data-parallel path executed on RCCL itself (backend nccl, one rank: all this box has): generator step,
-    discriminator step and combined step with the gradient all-reduced through torch.distributed must give the weights of
+    discriminator step and combined step with the gradient all-reduced by libsr_hip's ncclAllReduce on the ctx stream
+    (sr_train_allreduce / sr_rccl_allreduce_f32; the default) or through torch.distributed must give the weights of
     the plain single-process path (a one-rank mean is the identity)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q, direct))
     p.start()
     losses, w_gen, dl, gl, w_gen2, w_disc, its = q.get(timeout=300)
     p.join(timeout=60)
