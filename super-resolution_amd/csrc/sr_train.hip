@@ -9,6 +9,10 @@
 //   conv_tapsn.hip); the data gradient is the same convolution with mirrored, transposed weights
 //   weight gradients, transposed-conv data gradient, gathers: train_kernels.hip
 #include "sr_internal.h"
+
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include "sr_disc.h"
 #include "sr_vgg.h"
 
@@ -36,9 +40,13 @@ struct sr_train_state {
     unsigned char* clip_u8 = nullptr;   // max_batch HR frames as uint8
     double* mse_part = nullptr;
     float* d_loss = nullptr;            // [sr, flow]
-    // host batches: the two HR-sized inputs are copied on a second stream under FNet / the forward
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_est = nullptr, ev_hr = nullptr;
+    // host batches: the two HR-sized inputs are copied on a second stream under FNet / the forward, through page-locked
+    // staging filled by helper threads (HostUpload below): [est_tm1 | hr_t] of max_batch samples
+    static constexpr int MAX_UP = 8;
+    hipStream_t copy_stream[MAX_UP] = {};      // [0] also carries the copies the calling thread issues itself
+    hipEvent_t ev_start = nullptr, ev_est[MAX_UP] = {}, ev_hr[MAX_UP] = {};
+    unsigned char* h_stage = nullptr;
+    int up_threads = 2;                 // SR_H2D_THREADS (<= MAX_UP); 0: plain hipMemcpyAsync from the caller's arrays
 };
 
 namespace {
@@ -160,10 +168,13 @@ int train_init(sr_ctx* c) {
     const size_t mse_bytes = std::max(mse_workspace_bytes((long)(Bz * L0 * 16), 4), mse_workspace_bytes((long)(Bz * L0), 3));
     HIPCHK(c, hipMalloc((void**)&T->mse_part, mse_bytes));
     HIPCHK(c, hipMalloc((void**)&T->d_loss, 2 * sizeof(float)));
-    HIPCHK(c, hipStreamCreateWithFlags(&T->copy_stream, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&T->ev_start, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&T->ev_est, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&T->ev_hr, hipEventDisableTiming));
+    if (const char* e = getenv("SR_H2D_THREADS")) T->up_threads = std::max(0, std::min((int)sr_train_state::MAX_UP, atoi(e)));
+    for (int k = 0; k < std::max(1, T->up_threads); ++k) {
+        HIPCHK(c, hipStreamCreateWithFlags(&T->copy_stream[k], hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&T->ev_est[k], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&T->ev_hr[k], hipEventDisableTiming));
+    }
     return SR_OK;
 }
 
@@ -439,6 +450,78 @@ int train_backward(Tape& t, const float* d_lr_t, const float* d_lr_tm1, const fl
     return t.reduce_all();
 }
 
+// The two HR-sized HOST inputs of a batch (previous estimate, then the HR target: 31 MB each at 40 x 256 x 256) on their way to
+// the device.  hipMemcpyAsync from PAGEABLE memory blocks the calling thread for the whole transfer -- one thread's memcpy into
+// the runtime's staging, 1.03 - 1.1 ms per tensor -- so, issued behind FNet's launches, the first copy left the GPU idle for
+// 1.1 ms of every step (FNet of a 40 x 64 x 64 batch takes 0.25 ms) and the second held the backward's launches back (another
+// 0.3 ms in front of the loss).  Measured alternatives: helper threads issuing the pageable copies (they serialise inside the
+// runtime: no gain with 1, slower with 2 / 4); one thread's memcpy into own page-locked staging (as slow as the runtime's);
+// many 1 MiB DMAs on one stream (consecutive copies of a stream start ~25 us apart whatever their size: 20 GB/s).
+// What is built: `nw` helper threads, started before anything else, thread k on copy stream k.  Each memcpys its slice of the
+// estimate, then of the target, into page-locked staging in 4 MiB pieces and hands every piece to its stream as an
+// asynchronous DMA; the calling thread launches kernels meanwhile and calls done() where the ctx stream needs a tensor (that
+// waits until the helpers have ISSUED the stage -- an event must be recorded before a stream can wait for it --, records the
+// events and makes the ctx stream wait for them).  Two threads: the estimate is on the device 0.55 - 0.7 ms after the call
+// began (PCIe: 0.56 ms) and the step takes 8.7 instead of 9.2 ms; 3 or 4 threads measured slower again (8.9 - 9.1).
+// Helpers only report errors (no ctx access); the counters always reach `nw`, so done() cannot wait forever.
+struct HostUpload {
+    struct Job {
+        char* dst;
+        const char* src;
+        char* stage;
+    };
+    int nw = 0;
+    std::thread th[8];
+    std::mutex m;
+    std::condition_variable cv;
+    int finished[2] = {0, 0};      // helpers done with job 0 (estimate) / job 1 (target)
+    hipError_t err = hipSuccess;
+
+    void start(int device, const hipStream_t* streams, hipEvent_t after, int n_threads, Job j0, Job j1, size_t bytes) {
+        nw = n_threads;
+        for (int k = 0; k < nw; ++k) {
+            const size_t lo = (bytes / 4096 * k / nw) * 4096, hi = k + 1 == nw ? bytes : (bytes / 4096 * (k + 1) / nw) * 4096;
+            hipStream_t cs = streams[k];
+            th[k] = std::thread([this, device, cs, after, j0, j1, lo, hi] {
+                hipError_t e = hipSetDevice(device);
+                if (e == hipSuccess) e = hipStreamWaitEvent(cs, after, 0);
+                const Job jobs[2] = {j0, j1};
+                for (int j = 0; j < 2; ++j) {
+                    // few, large DMAs: consecutive copies of one stream start ~25 us apart whatever their size
+                    const size_t piece = (size_t)4 << 20;
+                    for (size_t o = lo; o < hi && e == hipSuccess && jobs[j].src; o += piece) {
+                        const size_t len = std::min(piece, hi - o);
+                        memcpy(jobs[j].stage + o, jobs[j].src + o, len);
+                        e = hipMemcpyAsync(jobs[j].dst + o, jobs[j].stage + o, len, hipMemcpyHostToDevice, cs);
+                    }
+                    {
+                        std::lock_guard<std::mutex> g(m);
+                        if (e != hipSuccess && err == hipSuccess) err = e;
+                        ++finished[j];
+                    }
+                    cv.notify_all();
+                }
+            });
+        }
+    }
+    // every piece of job j is on its copy stream: record the events behind them and make `st` wait for these
+    hipError_t done(int j, const hipStream_t* streams, hipEvent_t* evs, hipStream_t st) {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return finished[j] == nw; });
+        hipError_t e = err;
+        l.unlock();
+        for (int k = 0; k < nw && e == hipSuccess; ++k) {
+            e = hipEventRecord(evs[k], streams[k]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, evs[k], 0);
+        }
+        return e;
+    }
+    ~HostUpload() {
+        for (int k = 0; k < nw; ++k)
+            if (th[k].joinable()) th[k].join();
+    }
+};
+
 // n_clips > 0 (sr_train_clips_grads): est_tm1 is the frame-major estimate buffer, n_clips zero frames followed by room
 // for the estimates of all B samples, which the forward fills frame group by frame group
 int grads_common(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1, const float* hr_t,
@@ -456,12 +539,21 @@ int grads_common(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const
     const size_t nlr = (size_t)B * c->h * c->w * 3 * 4, nhr = nlr * 16;
     hipStream_t st = c->stream;
     const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    // The two HR-sized inputs (31 MB each at 40 x 256 x 256) go over a second stream: a copy from pageable
-    // host memory blocks the calling thread, so FNet is enqueued first and runs under the copy of the
-    // previous estimate, the rest of the forward under the copy of the HR target.
-    hipStream_t cs = T->copy_stream;
+    // The two HR-sized inputs (31 MB each at 40 x 256 x 256) go over a second stream: FNet runs under the copy of the
+    // previous estimate, the rest of the forward under the copy of the HR target (host arrays: HostUpload above).
+    hipStream_t cs = T->copy_stream[0];
     HIPCHK(c, hipEventRecord(T->ev_start, st));                 // earlier work on the ctx stream may still read the buffers
-    HIPCHK(c, hipStreamWaitEvent(cs, T->ev_start, 0));
+    HostUpload up;                                              // joins its threads on every way out of this function
+    const bool staged = !dev && n_clips == 0 && T->up_threads > 0 && nhr >= ((size_t)1 << 20);
+    if (staged) {
+        const size_t cap_hr = (size_t)c->max_batch * c->h * c->w * 48 * 4;
+        if (!T->h_stage) HIPCHK(c, hipHostMalloc((void**)&T->h_stage, 2 * cap_hr, hipHostMallocDefault));
+        // the staging is free again when this call returns: it ends with a synchronisation behind every copy
+        up.start(c->device, T->copy_stream, T->ev_start, T->up_threads, {(char*)c->d_est[0], (const char*)est_tm1, (char*)T->h_stage},
+                 {(char*)T->act["hr"], hr_t != T->act["hr"] ? (const char*)hr_t : nullptr, (char*)T->h_stage + cap_hr}, nhr);
+    } else {
+        HIPCHK(c, hipStreamWaitEvent(cs, T->ev_start, 0));
+    }
     HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, kind, st));
     HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, lr_tm1, nlr, kind, st));
     Tape t{c, T, B, c->prec, st};
@@ -486,14 +578,22 @@ int grads_common(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const
                 return rc;
         }
     } else {
-        HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, kind, cs));
-        HIPCHK(c, hipEventRecord(T->ev_est, cs));
-        HIPCHK(c, hipStreamWaitEvent(st, T->ev_est, 0));
-        if ((rc = train_forward(t, 2, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
+        if (staged) {
+            HIPCHK(c, up.done(0, T->copy_stream, T->ev_est, st));
+        } else {
+            HIPCHK(c, hipMemcpyAsync(c->d_est[0], est_tm1, nhr, kind, cs));
+            HIPCHK(c, hipEventRecord(T->ev_est[0], cs));
+            HIPCHK(c, hipStreamWaitEvent(st, T->ev_est[0], 0));
+        }
+            if ((rc = train_forward(t, 2, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
     }
-    if (hr_t != T->act["hr"]) HIPCHK(c, hipMemcpyAsync(T->act["hr"], hr_t, nhr, kind, cs));
-    HIPCHK(c, hipEventRecord(T->ev_hr, cs));
-    HIPCHK(c, hipStreamWaitEvent(st, T->ev_hr, 0));
+    if (staged) {
+        HIPCHK(c, up.done(1, T->copy_stream, T->ev_hr, st));
+    } else {
+        if (hr_t != T->act["hr"]) HIPCHK(c, hipMemcpyAsync(T->act["hr"], hr_t, nhr, kind, cs));
+        HIPCHK(c, hipEventRecord(T->ev_hr[0], cs));
+        HIPCHK(c, hipStreamWaitEvent(st, T->ev_hr[0], 0));
+    }
     if ((rc = train_backward(t, c->d_lr_t, c->d_lr_tm1, est_prev_all, T->act["hr"], est_all, c->d_lr_warp, c->d_flow))) return rc;
     if (d_grads_out) HIPCHK(c, hipMemcpyAsync(d_grads_out, T->d_grad, (size_t)T->nparams * 4, hipMemcpyDeviceToDevice, st));
     float l[2] = {0.f, 0.f};
@@ -557,12 +657,16 @@ void train_free(sr_ctx* c) {
     if (T->mse_part) (void)hipFree(T->mse_part);
     for (void* p : {(void*)T->clip_lr, (void*)T->clip_est, (void*)T->clip_u8})
         if (p) (void)hipFree(p);
-    if (T->copy_stream) {
-        (void)hipStreamSynchronize(T->copy_stream);
-        (void)hipStreamDestroy(T->copy_stream);
-    }
-    for (hipEvent_t e : {T->ev_start, T->ev_est, T->ev_hr})
-        if (e) (void)hipEventDestroy(e);
+    for (hipStream_t cs : T->copy_stream)
+        if (cs) {
+            (void)hipStreamSynchronize(cs);
+            (void)hipStreamDestroy(cs);
+        }
+    if (T->h_stage) (void)hipHostFree(T->h_stage);
+    if (T->ev_start) (void)hipEventDestroy(T->ev_start);
+    for (int k = 0; k < sr_train_state::MAX_UP; ++k)
+        for (hipEvent_t e : {T->ev_est[k], T->ev_hr[k]})
+            if (e) (void)hipEventDestroy(e);
     for (auto& kv : T->act) (void)hipFree(kv.second);
     for (auto& L : T->fnet_dg) free_layer(L);
     for (auto& L : T->srnet_dg) free_layer(L);

@@ -8,6 +8,7 @@ well conditioned (conditioned_data below), 1e-2 in bf16x3 (kink-flip noise, expl
 1e-5 relative; two Adam steps move the weights like Keras 2.2.4's Adam to within 2 % of the step size.  Parity is unpinned by the
 reference itself (no Keras / TF here), exactly as for the forward path."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -315,6 +316,34 @@ def test_device_pointer_entry_points(sh, weights7):
         np.testing.assert_array_equal(a, b)
     ctx.close()
     ctx2.close()
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_host_batches_through_the_upload_threads(sh, weights7, threads):
+    """sr_train.hip HostUpload: the HR-sized host inputs (>= 1 MiB) go to the device from helper threads through page-locked
+    staging, SR_H2D_THREADS of them (read when a ctx first trains; default 2); 0 = plain copies from the caller's arrays.  Same
+    bytes on the device either way: losses and gradients are bit-identical, also on a second call (the staging is reused) with
+    another batch, with a smaller batch, and with slices that do not divide evenly."""
+    B, h, w = 8, 32, 32                                  # 8 (then 6) x 128 x 128 x 3 x 4 B = 1.5 (1.1) MiB per HR tensor
+    batches = [step_data(1200, B, h, w), step_data(1201, B, h, w), step_data(1202, B - 2, h, w)]
+
+    def run(n):
+        os.environ["SR_H2D_THREADS"] = str(n)
+        try:
+            ctx = sh.Context(h, w, max_batch=B, dtype="fp32")
+            ctx.load_weights(weights7)
+            out = [ctx.train_grads(*d, read=True) for d in batches]
+            ctx.close()
+        finally:
+            os.environ.pop("SR_H2D_THREADS", None)
+        return out
+
+    want = run(0)
+    got = run(threads)
+    assert not np.array_equal(want[0][1], want[1][1])
+    for (l0, g0), (l1, g1) in zip(want, got):
+        assert list(l0) == list(l1)
+        np.testing.assert_array_equal(g0, g1)
 
 
 @pytest.mark.parametrize("dtype,model", [("fp32", "frvsr"), ("bf16x3", "frvsr"), ("fp32", "tecogan")])
