@@ -367,6 +367,12 @@ class Context:
         _check(lib().sr_train_read_grads(self._h, _ptr(g)), self._h)
         return list(losses), g
 
+    def train_read_grads(self):
+        """The ctx's own flat gradient (of the last train_grads / train_clips_grads, or what train_allreduce left there)."""
+        g = np.empty(self.param_count(), np.float32)
+        _check(lib().sr_train_read_grads(self._h, _ptr(g)), self._h)
+        return g
+
     def train_allreduce(self, comm, d_grads=None):
         """Sum of the flat gradient over the ranks of `comm` (RcclComm), in place, on this ctx's stream (include/sr_hip.h)."""
         _check(lib().sr_train_allreduce(self._h, comm.handle, _vp(d_grads) if d_grads else None), self._h)

@@ -129,6 +129,23 @@ def _rccl_worker(port, out, direct):
         t = torch.arange(1000, dtype=torch.float32, device="cuda:0")
         dp._comm.allreduce_f32(t.data_ptr(), t.numel())
         assert dp._comm.nranks == 1 and np.array_equal(t.cpu().numpy(), np.arange(1000, dtype=np.float32))
+        # the C-level sequence of INTEGRATION.md on the ctx's OWN gradient buffer: grads -> all-reduce -> apply, no host wait
+        # in between; one rank: the gradient and the step are those of the plain sequence
+        import sr_hip
+        plain = sr_hip.Context(16, 16, max_batch=2, dtype="fp32")
+        plain.load_weights(rn.make_weights(seed=7))
+        _, g_plain = plain.train_grads(a, b, c, hr, read=True)
+        plain.train_apply(lr=1e-4)
+        seq = sr_hip.Context(16, 16, max_batch=2, dtype="fp32")
+        seq.load_weights(rn.make_weights(seed=7))
+        seq.train_grads(a, b, c, hr)
+        seq.train_allreduce(dp._comm)
+        assert np.array_equal(seq.train_read_grads(), g_plain)
+        seq.train_apply(grad_scale=1.0 / dp._comm.nranks, lr=1e-4)
+        for (_, x), (_, y) in zip(seq.get_weights(), plain.get_weights()):
+            assert np.array_equal(x, y)
+        plain.close()
+        seq.close()
     w_gen = [x.copy() for x in m.get_weights()]
     # the adversarial models use the same path: discriminator step and combined step through RCCL
     d = Discriminator((64, 64, 3), device=0).build()
