@@ -54,7 +54,16 @@ static int pass_tap_h(int mode, int pass, int t) {
     return mode == M_CONV ? t : T[pass][t];
 }
 
-void plan_layer(ConvLayer& L, int prec, int mode, int cin, int cout) {
+// tiles: 8 x 32-pixel tiles of the largest launch this layer will see (0: unknown).  conv3x3_lds_kernel runs two persistent
+// workgroups per CU; with 64 output channels per workgroup (nt = 2) a launch of few tiles rounds up badly -- the reference's
+// training batch, 40 x 64 x 64, is 640 tiles on 512 slots: 64 CUs get two workgroups of two tiles, 192 get one -- so such layers
+// are planned with 32 output channels per workgroup (nt = 1): twice the workgroup-tiles at ~0.6 of the cost each.  Measured on
+// the training step: forward convs 2.11 -> 1.95 ms, stride-1 data gradients 1.71 -> 1.49 ms with every kernel bracketed by
+// events, 8.4 -> 8.2 ms for the step as a whole.  The K order of an output channel
+// does not depend on nt: results are bit-identical either way.
+long conv_tiles(int B, int H, int W) { return (long)B * ((H + 7) / 8) * ((W + 31) / 32); }
+
+void plan_layer(ConvLayer& L, int prec, int mode, int cin, int cout, long tiles) {
     L.mode = mode;
     L.cin = cin;
     L.cout = cout;
@@ -77,6 +86,8 @@ void plan_layer(ConvLayer& L, int prec, int mode, int cin, int cout) {
     L.steps = steps;
     L.nchunk = total_steps / steps;
     L.nt = (mode == M_CONVT || cout > 32) ? 2 : 1;
+    // (not for plain bf16: that ctx cannot train, and its inference measured 1.5 % slower this way)
+    if (mode == M_CONV && L.nt == 2 && prec != P_BF16 && tiles > 0 && tiles * ((cout + 63) / 64) < 1280 && !getenv("SR_NO_NT1")) L.nt = 1;
     L.ncb = (cout + 32 * L.nt - 1) / (32 * L.nt);
     const int bv = prec == P_BF16X3 ? 2 : 1;
     L.wstride_cb = L.nchunk * 9 * L.steps * L.nt * bv * 64;
@@ -1106,14 +1117,15 @@ int sr_commit_weights(sr_ctx* c) {
         return fail(c, SR_ERR_WEIGHTS, "expected 28 FNet + 48 SRNet tensors, have %d + %d", c->n_fnet, c->n_srnet);
     HIPCHK(c, hipSetDevice(c->device));
     for (int i = 0; i < 14; ++i) {
-        plan_layer(c->fnet[i], c->prec, M_CONV, FNET_SPEC[i][0], FNET_SPEC[i][1]);
+        const int lvl[14] = {0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 1, 1, 0, 0};
+        plan_layer(c->fnet[i], c->prec, M_CONV, FNET_SPEC[i][0], FNET_SPEC[i][1], conv_tiles(c->max_batch, c->h >> lvl[i], c->w >> lvl[i]));
         int rc = upload_layer(c, c->fnet[i], c->prec, c->tensors[2 * i].data.data(), c->tensors[2 * i + 1].data.data());
         if (rc) return rc;
     }
     for (int i = 0; i < 24; ++i) {
         int cin, cout, mode;
         srnet_spec(i, cin, cout, mode);
-        plan_layer(c->srnet[i], c->prec, mode, cin, cout);
+        plan_layer(c->srnet[i], c->prec, mode, cin, cout, conv_tiles(c->max_batch, c->h << (i == 23 ? 2 : 0), c->w << (i == 23 ? 2 : 0)));
         int rc = upload_layer(c, c->srnet[i], c->prec, c->tensors[28 + 2 * i].data.data(), c->tensors[28 + 2 * i + 1].data.data());
         if (rc) return rc;
     }

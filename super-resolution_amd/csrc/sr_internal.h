@@ -157,7 +157,8 @@ int fail(sr_ctx* c, int code, const char* fmt, ...);
     } while (0)
 
 // weights
-void plan_layer(ConvLayer& L, int prec, int mode, int cin, int cout);
+long conv_tiles(int B, int H, int W);
+void plan_layer(ConvLayer& L, int prec, int mode, int cin, int cout, long tiles = 0);
 std::vector<PackEnt> pack_entries(const ConvLayer& L, int prec, int kind, bool kperm = false);
 std::vector<PackEnt> trunk_entries(int cin, int cout);
 std::vector<PackEnt> trunkT_entries(int cin, int cout);

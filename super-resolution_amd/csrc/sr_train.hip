@@ -134,7 +134,9 @@ int train_init(sr_ctx* c) {
             part_bytes += round_up_sz(wgrad_workspace_bytes(B, H, W, cin, cout, mode == M_CONVT));
             if ((mode == M_CONVT && c->prec != P_BF16X3) || (is_f && i == 0) || cout <= 3) continue;   // <= 3 outputs: dgrad_few reads the master weights
             ConvLayer& D = is_f ? T->fnet_dg[i] : T->srnet_dg[i];
-            plan_layer(D, c->prec, M_CONV, cout, cin);
+            // the stride-1 data gradient is a conv of the layer's own launch size (H x W is its input = the gradient's output);
+            // dgrad_s2_x3 reads the forward packing of a transposed conv and is faster with 64 channels per block: no hint
+            plan_layer(D, c->prec, M_CONV, cout, cin, mode == M_CONVT ? 0 : conv_tiles(B, H, W));
             const float* wk = c->tensors[(is_f ? 0 : 28) + 2 * i].data.data();
             // transposed conv (bf16x3): its kernel (kh,kw,out,in) read as HWIO is the stride-2 data-gradient conv's
             // kernel; dgrad_s2_x3 reads it in the forward packing

@@ -318,6 +318,34 @@ def test_device_pointer_entry_points(sh, weights7):
     ctx2.close()
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_output_channel_blocking_does_not_change_results(sh, weights7, dtype):
+    """sr_api.hip plan_layer: layers whose largest launch has few tiles (every layer of a ctx this small, and of the reference's
+    40 x 64 x 64 training batch) run conv3x3_lds_kernel with 32 output channels per workgroup instead of 64 (SR_NO_NT1=1: always
+    64).  An output channel's sum runs in the same order either way: the step and every gradient are bit-identical."""
+    B, h, w = 2, 24, 40
+    data = step_data(1300, B, h, w)
+
+    def run(no_nt1):
+        if no_nt1:
+            os.environ["SR_NO_NT1"] = "1"
+        try:
+            ctx = sh.Context(h, w, max_batch=B, dtype=dtype)
+            ctx.load_weights(weights7)
+            est, lw = ctx.step(*data[:3])
+            losses, g = ctx.train_grads(*data, read=True)
+            ctx.close()
+        finally:
+            os.environ.pop("SR_NO_NT1", None)
+        return est, lw, losses, g
+
+    a, b = run(False), run(True)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    assert list(a[2]) == list(b[2])
+    np.testing.assert_array_equal(a[3], b[3])
+
+
 @pytest.mark.parametrize("threads", [1, 3, 8])
 def test_host_batches_through_the_upload_threads(sh, weights7, threads):
     """sr_train.hip HostUpload: the HR-sized host inputs (>= 1 MiB) go to the device from helper threads through page-locked
