@@ -549,15 +549,24 @@ int grads_common(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const
     const bool staged = !dev && n_clips == 0 && T->up_threads > 0 && nhr >= ((size_t)1 << 20);
     if (staged) {
         const size_t cap_hr = (size_t)c->max_batch * c->h * c->w * 48 * 4;
-        if (!T->h_stage) HIPCHK(c, hipHostMalloc((void**)&T->h_stage, 2 * cap_hr, hipHostMallocDefault));
+        if (!T->h_stage) HIPCHK(c, hipHostMalloc((void**)&T->h_stage, 2 * cap_hr + cap_hr / 8, hipHostMallocDefault));   // + the two LR tensors
         // the staging is free again when this call returns: it ends with a synchronisation behind every copy
         up.start(c->device, T->copy_stream, T->ev_start, T->up_threads, {(char*)c->d_est[0], (const char*)est_tm1, (char*)T->h_stage},
                  {(char*)T->act["hr"], hr_t != T->act["hr"] ? (const char*)hr_t : nullptr, (char*)T->h_stage + cap_hr}, nhr);
     } else {
         HIPCHK(c, hipStreamWaitEvent(cs, T->ev_start, 0));
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, kind, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, lr_tm1, nlr, kind, st));
+    if (staged) {
+        // the two LR tensors the same way from this thread (as pageable copies they held FNet's first launch back by 0.2 ms)
+        unsigned char* h_lr = T->h_stage + 2 * (size_t)c->max_batch * c->h * c->w * 48 * 4;
+        memcpy(h_lr, lr_t, nlr);
+        HIPCHK(c, hipMemcpyAsync(c->d_lr_t, h_lr, nlr, hipMemcpyHostToDevice, st));
+        memcpy(h_lr + nlr, lr_tm1, nlr);
+        HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, h_lr + nlr, nlr, hipMemcpyHostToDevice, st));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->d_lr_t, lr_t, nlr, kind, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_lr_tm1, lr_tm1, nlr, kind, st));
+    }
     Tape t{c, T, B, c->prec, st};
     if ((rc = train_forward(t, 1, c->d_lr_t, c->d_lr_tm1, c->d_est[0], c->d_est[1], c->d_lr_warp, c->d_flow))) return rc;
     const float* est_prev_all = c->d_est[0];
