@@ -40,6 +40,7 @@ struct sr_train_state {
     unsigned char* clip_u8 = nullptr;   // max_batch HR frames as uint8
     double* mse_part = nullptr;
     float* d_loss = nullptr;            // [sr, flow]
+    float* h_loss = nullptr;            // the same two values in page-locked host memory (read after a synchronisation)
     // host batches: the two HR-sized inputs are copied on a second stream under FNet / the forward, through page-locked
     // staging filled by helper threads (HostUpload below): [est_tm1 | hr_t] of max_batch samples
     static constexpr int MAX_UP = 8;
@@ -170,6 +171,7 @@ int train_init(sr_ctx* c) {
     const size_t mse_bytes = std::max(mse_workspace_bytes((long)(Bz * L0 * 16), 4), mse_workspace_bytes((long)(Bz * L0), 3));
     HIPCHK(c, hipMalloc((void**)&T->mse_part, mse_bytes));
     HIPCHK(c, hipMalloc((void**)&T->d_loss, 2 * sizeof(float)));
+    HIPCHK(c, hipHostMalloc((void**)&T->h_loss, 2 * sizeof(float), hipHostMallocDefault));
     HIPCHK(c, hipEventCreateWithFlags(&T->ev_start, hipEventDisableTiming));
     if (const char* e = getenv("SR_H2D_THREADS")) T->up_threads = std::max(0, std::min((int)sr_train_state::MAX_UP, atoi(e)));
     for (int k = 0; k < std::max(1, T->up_threads); ++k) {
@@ -524,6 +526,21 @@ struct HostUpload {
     }
 };
 
+// sr_train_on_batch / sr_train_on_clips enqueue the optimizer step behind the backward pass BEFORE they wait for the losses
+// (waiting in between left the GPU idle for ~50 us of every step: the host's wake-up plus the Adam launch)
+thread_local bool g_defer_loss_sync = false;
+
+int finish_losses(sr_ctx* c, float* losses) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const float* l = c->train->h_loss;
+    if (losses) {   // Keras train_on_batch order: [total, output 1, output 2] (reference FRVSR.py:161)
+        losses[0] = l[0] + l[1];
+        losses[1] = l[0];
+        losses[2] = l[1];
+    }
+    return SR_OK;
+}
+
 // n_clips > 0 (sr_train_clips_grads): est_tm1 is the frame-major estimate buffer, n_clips zero frames followed by room
 // for the estimates of all B samples, which the forward fills frame group by frame group
 int grads_common(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1, const float* hr_t,
@@ -607,15 +624,9 @@ int grads_common(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const
     }
     if ((rc = train_backward(t, c->d_lr_t, c->d_lr_tm1, est_prev_all, T->act["hr"], est_all, c->d_lr_warp, c->d_flow))) return rc;
     if (d_grads_out) HIPCHK(c, hipMemcpyAsync(d_grads_out, T->d_grad, (size_t)T->nparams * 4, hipMemcpyDeviceToDevice, st));
-    float l[2] = {0.f, 0.f};
-    HIPCHK(c, hipMemcpyAsync(l, T->d_loss, sizeof l, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    if (losses) {   // Keras train_on_batch order: [total, output 1, output 2] (reference FRVSR.py:161)
-        losses[0] = l[0] + l[1];
-        losses[1] = l[0];
-        losses[2] = l[1];
-    }
-    return SR_OK;
+    HIPCHK(c, hipMemcpyAsync(T->h_loss, T->d_loss, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (g_defer_loss_sync) return SR_OK;      // sr_train_on_batch / sr_train_on_clips: the Adam step is enqueued first
+    return finish_losses(c, losses);
 }
 
 // packed MFMA buffers of every conv (forward, data gradient, fused tap projection) from the master weights
@@ -674,6 +685,7 @@ void train_free(sr_ctx* c) {
             (void)hipStreamDestroy(cs);
         }
     if (T->h_stage) (void)hipHostFree(T->h_stage);
+    if (T->h_loss) (void)hipHostFree(T->h_loss);
     if (T->ev_start) (void)hipEventDestroy(T->ev_start);
     for (int k = 0; k < sr_train_state::MAX_UP; ++k)
         for (hipEvent_t e : {T->ev_est[k], T->ev_hr[k]})
@@ -761,9 +773,12 @@ int sr_train_apply(sr_ctx* c, const float* d_grads, float grad_scale, float lr, 
 
 int sr_train_on_batch(sr_ctx* c, int B, const float* lr_t, const float* lr_tm1, const float* est_tm1, const float* hr_t,
                       float lr, float* losses) {
+    g_defer_loss_sync = true;
     int rc = grads_common(c, B, lr_t, lr_tm1, est_tm1, hr_t, nullptr, losses, false);
+    g_defer_loss_sync = false;
     if (rc) return rc;
-    return sr_train_apply(c, nullptr, 1.f, lr, 0.9f, 0.999f, 1e-7f);
+    if ((rc = sr_train_apply(c, nullptr, 1.f, lr, 0.9f, 0.999f, 1e-7f))) return rc;
+    return finish_losses(c, losses);
 }
 
 // Training iteration from HR clips (reference FRVSR.py:103-156 without its per-sample host round trips):
@@ -810,9 +825,12 @@ int sr_train_clips_grads(sr_ctx* c, int n_clips, int c_frames, const void* hr, i
 }
 
 int sr_train_on_clips(sr_ctx* c, int n_clips, int c_frames, const void* hr, int hr_is_u8, float lr, float* losses) {
+    g_defer_loss_sync = true;
     int rc = sr_train_clips_grads(c, n_clips, c_frames, hr, hr_is_u8, nullptr, losses);
+    g_defer_loss_sync = false;
     if (rc) return rc;
-    return sr_train_apply(c, nullptr, 1.f, lr, 0.9f, 0.999f, 1e-7f);
+    if ((rc = sr_train_apply(c, nullptr, 1.f, lr, 0.9f, 0.999f, 1e-7f))) return rc;
+    return finish_losses(c, losses);
 }
 
 int64_t sr_train_iterations(const sr_ctx* c) { return (c && c->train) ? c->train->t : 0; }
