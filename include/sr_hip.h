@@ -129,7 +129,10 @@ int sr_clip_push_dev(sr_ctx* ctx, const float* lr_t, float* est_t);
  * pointer (lr_on_device = 0; page-locked for an asynchronous copy) or a device pointer.  The call returns once the
  * work is enqueued: est_u8_host is complete after sr_u8_wait(ctx, 0) (or sr_sync); sr_u8_wait(ctx, 1) returns
  * when every frame but the newest has landed -- the pattern is push(t) into buffer t % 2, then
- * sr_u8_wait(ctx, 1), then consume buffer (t-1) % 2. */
+ * sr_u8_wait(ctx, 1), then consume buffer (t-1) % 2.  Host LR frames are copied in on a third stream when the call is made,
+ * i.e. under the kernels of the previous push.  The device serves copies in submission order, so the copy-out of frame t is
+ * SUBMITTED by push t+1 (behind that push's copy-in) or by sr_u8_wait(ctx, 0) / sr_sync / sr_clip_begin: a frame that is
+ * followed by neither never reaches the host.  lr_t must stay valid until the step that reads it has run (as before). */
 int sr_clip_push_u8(sr_ctx* ctx, const float* lr_t, int lr_on_device, uint8_t* est_u8_host);
 int sr_u8_wait(sr_ctx* ctx, int keep_in_flight);
 
@@ -143,7 +146,8 @@ int sr_clip_read_est(sr_ctx* ctx, int first, int n, float* est);
  * `est` -- page-locked memory (sr_host_alloc), or the copy is not asynchronous -- on a stream of its own, ordered after the
  * step that produced them; the caller may push the next frame at once.  The push after that one waits on the device until the
  * copy is over (it overwrites the buffer being read).  _end blocks the host until `est` is valid.  One read-back at a time:
- * _begin before the previous _end is SR_ERR_STATE, as is _end without _begin.  No counterpart in the reference (its
+ * _begin before the previous _end is SR_ERR_STATE, as is _end without _begin.  The copy is submitted by the next push (behind
+ * its copy-in, for the same reason as the uint8 frames') or by _end.  No counterpart in the reference (its
  * predict_on_batch returns every float frame to the host, FRVSR.py:292-296). */
 int sr_clip_read_est_begin(sr_ctx* ctx, int first, int n, float* est);
 int sr_clip_read_est_end(sr_ctx* ctx);

@@ -877,6 +877,15 @@ int put_in(sr_ctx* c, float* d_dst, const float* src, bool src_dev, int B, int s
     return SR_OK;
 }
 
+// submits the float read-back that sr_clip_read_est_begin left pending (see there)
+int est_flush(sr_ctx* c) {
+    if (!c->est_copy_dst) return SR_OK;
+    HIPCHK(c, hipMemcpyAsync(c->est_copy_dst, c->est_copy_src, c->est_copy_bytes, hipMemcpyDeviceToHost, c->est_stream));
+    HIPCHK(c, hipEventRecord(c->ev_est_done, c->est_stream));
+    c->est_copy_dst = nullptr;
+    return SR_OK;
+}
+
 int get_out(sr_ctx* c, float* dst, bool dst_dev, const float* d_src, int B, int scale, int ch) {
     hipStream_t st = c->stream;
     const int rows = scale * c->h_in, cols = scale * c->w_in;
@@ -886,7 +895,11 @@ int get_out(sr_ctx* c, float* dst, bool dst_dev, const float* d_src, int B, int 
         return SR_OK;
     }
     float* stage = (size_t)rows * cols * ch > (size_t)c->h_in * c->w_in * 3 ? c->d_io_hr : c->d_io_lr;
-    if (c->est_pending && !dst_dev && stage == c->d_io_hr) HIPCHK(c, hipStreamWaitEvent(st, c->ev_est_done, 0));   // sr_clip_read_est_begin is reading it
+    if (c->est_pending && !dst_dev && stage == c->d_io_hr) {   // sr_clip_read_est_begin is reading it
+        int rc = est_flush(c);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_est_done, 0));
+    }
     float* ddst = dst_dev ? dst : stage;
     LAUNCHCHK(c, "crop_copy", launch_crop_copy(d_src, ddst, B, rows, cols, ch, scale * c->h, scale * c->w, st));
     if (!dst_dev) HIPCHK(c, hipMemcpyAsync(dst, stage, n, hipMemcpyDeviceToHost, st));
@@ -904,8 +917,18 @@ void free_u8_path(sr_ctx* c) {
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     c->copy_stream = nullptr;
+    for (int i = 0; i < 2; ++i) {
+        if (c->d_in[i]) (void)hipFree(c->d_in[i]);
+        if (c->ev_in_ready[i]) (void)hipEventDestroy(c->ev_in_ready[i]);
+        if (c->ev_in_free[i]) (void)hipEventDestroy(c->ev_in_free[i]);
+        c->d_in[i] = nullptr;
+        c->ev_in_ready[i] = c->ev_in_free[i] = nullptr;
+    }
+    if (c->in_stream) (void)hipStreamDestroy(c->in_stream);
+    c->in_stream = nullptr;
     c->u8_ready = false;
     c->u8_pushes = 0;
+    c->u8_pending_host = nullptr;
     if (c->est_stream) (void)hipStreamDestroy(c->est_stream);
     if (c->ev_est_src) (void)hipEventDestroy(c->ev_est_src);
     if (c->ev_est_done) (void)hipEventDestroy(c->ev_est_done);
@@ -913,6 +936,7 @@ void free_u8_path(sr_ctx* c) {
     c->ev_est_src = c->ev_est_done = nullptr;
     c->est_guard = 0;
     c->est_pending = false;
+    c->est_copy_dst = nullptr;
 }
 
 }  // namespace srh
@@ -1061,9 +1085,13 @@ int sr_set_stream(sr_ctx* c, void* hip_stream) {
     return SR_OK;
 }
 
+static int u8_flush(sr_ctx* c);
+
 int sr_sync(sr_ctx* c) {
     if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
     HIPCHK(c, hipSetDevice(c->device));
+    int rc = u8_flush(c);      // the newest uint8 frame's copy is still pending (sr_clip_push_u8)
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     return SR_OK;
@@ -1245,6 +1273,7 @@ int sr_clip_begin(sr_ctx* c, int B) {
     // state0 = zeros for prev LR and prev estimate (reference FRVSR.py:233-234)
     HIPCHK(c, hipMemsetAsync(c->d_lr_tm1, 0, nlr, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_est[0], 0, nlr * 16, c->stream));
+    if ((rc = u8_flush(c))) return rc;      // a previous clip's last uint8 frame, if its caller never waited for it
     c->cur = 0;
     c->clip_B = B;
     c->clip_active = true;
@@ -1258,9 +1287,12 @@ static int clip_push_common(sr_ctx* c, const float* lr_t, float* est_t, bool dev
     HIPCHK(c, hipSetDevice(c->device));
     const int B = c->clip_B;
     hipStream_t st = c->stream;
+    // a float read-back left pending by sr_clip_read_est_begin: submitted now, behind this push's own input copy if it has one
+    int rc = est_flush(c);
+    if (rc) return rc;
     // sr_clip_read_est_begin is still copying the estimate of two pushes ago out of the buffer this step writes
     if (c->est_guard > 0 && --c->est_guard == 0) HIPCHK(c, hipStreamWaitEvent(st, c->ev_est_done, 0));
-    int rc = put_in(c, c->d_lr_t, lr_t, dev, B, 1, 3);
+    rc = put_in(c, c->d_lr_t, lr_t, dev, B, 1, 3);
     if (rc) return rc;
     float* out = c->d_est[c->cur ^ 1];
     rc = run_step(c, B, c->d_lr_t, c->d_lr_tm1, c->d_est[c->cur], out, nullptr, nullptr, false);
@@ -1278,6 +1310,17 @@ static int clip_push_common(sr_ctx* c, const float* lr_t, float* est_t, bool dev
 int sr_clip_push(sr_ctx* c, const float* lr_t, float* est_t) { return clip_push_common(c, lr_t, est_t, false, true); }
 int sr_clip_push_dev(sr_ctx* c, const float* lr_t, float* est_t) { return clip_push_common(c, lr_t, est_t, true, false); }
 
+// submits the pending uint8 frame's copy to the host (the kernel cropped rows and columns: one dense copy)
+static int u8_flush(sr_ctx* c) {
+    if (!c->u8_pending_host) return SR_OK;
+    const int slot = c->u8_pending_slot;
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_u8_ready[slot], 0));
+    HIPCHK(c, hipMemcpyAsync(c->u8_pending_host, c->d_u8[slot], c->u8_pending_bytes, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->ev_u8_done[slot], c->copy_stream));
+    c->u8_pending_host = nullptr;
+    return SR_OK;
+}
+
 int sr_clip_push_u8(sr_ctx* c, const float* lr_t, int lr_on_device, uint8_t* est_u8_host) {
     if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
     if (!est_u8_host) return fail(c, SR_ERR_ARG, "est_u8_host is NULL");
@@ -1285,11 +1328,15 @@ int sr_clip_push_u8(sr_ctx* c, const float* lr_t, int lr_on_device, uint8_t* est
     if (!c->clip_active) return fail(c, SR_ERR_STATE, "sr_clip_push_u8 without sr_clip_begin");   // before anything is allocated
     if (!c->u8_ready) {   // first use: the copy stream, two device frames and their events; ready only when ALL of them exist
         const size_t n = (size_t)c->max_batch * 16 * c->h_in * c->w_in * 3;
-        bool ok = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
+        bool ok = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&c->in_stream, hipStreamNonBlocking) == hipSuccess;
         for (int i = 0; i < 2 && ok; ++i)
             ok = hipMalloc((void**)&c->d_u8[i], n) == hipSuccess &&
+                 hipMalloc((void**)&c->d_in[i], (size_t)c->max_batch * c->h_in * c->w_in * 3 * sizeof(float)) == hipSuccess &&
                  hipEventCreateWithFlags(&c->ev_u8_ready[i], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&c->ev_u8_done[i], hipEventDisableTiming) == hipSuccess;
+                 hipEventCreateWithFlags(&c->ev_u8_done[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&c->ev_in_ready[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&c->ev_in_free[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) {   // leave nothing half made: the next call starts over
             (void)hipGetLastError();
             free_u8_path(c);
@@ -1297,18 +1344,38 @@ int sr_clip_push_u8(sr_ctx* c, const float* lr_t, int lr_on_device, uint8_t* est
         }
         c->u8_ready = true;
     }
-    int rc = clip_push_common(c, lr_t, nullptr, lr_on_device != 0, false);   // no fp32 copy out, no synchronisation
-    if (rc) return rc;
     const int B = c->clip_B, slot = (int)(c->u8_pushes & 1);
+    if (!lr_t) return fail(c, SR_ERR_ARG, "lr_t is NULL");
+    // Host frames go to the device on a stream of their own, now, under the previous push's kernels, into d_in[slot] (free
+    // again when the step that used it two pushes ago has copied it on); on the ctx stream the copy would wait for those
+    // kernels, 0.2 ms per step in the open.  The copy engine serves copies in SUBMISSION order, so the previous frame's
+    // uint8 D2H -- which waits for that frame's kernels -- must be submitted AFTER this copy, not before: it is kept pending by
+    // the push that produced it and submitted here (or by sr_u8_wait(ctx, 0)).  Submitted first, it held this copy and with it
+    // the whole step back by a D2H (measured 7.1 instead of 6.0 ms per step); a copy kernel reading the page-locked frames
+    // instead starved behind the trunk kernels, which own every register of the CUs they run on (7.2 ms).
+    bool early = false;
+    if (!lr_on_device) {
+        if (c->u8_pushes >= 2) HIPCHK(c, hipStreamWaitEvent(c->in_stream, c->ev_in_free[slot], 0));
+        HIPCHK(c, hipMemcpyAsync(c->d_in[slot], lr_t, (size_t)B * c->h_in * c->w_in * 3 * sizeof(float), hipMemcpyHostToDevice, c->in_stream));
+        HIPCHK(c, hipEventRecord(c->ev_in_ready[slot], c->in_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in_ready[slot], 0));
+        lr_t = c->d_in[slot];
+        early = true;
+    }
+    int rc0 = u8_flush(c);
+    if (rc0) return rc0;
+    int rc = clip_push_common(c, lr_t, nullptr, lr_on_device != 0 || early, false);   // no fp32 copy out, no synchronisation
+    if (early) HIPCHK(c, hipEventRecord(c->ev_in_free[slot], c->stream));   // (also after a failed step: the slot's next user waits for it)
+    if (rc) return rc;
     const float* est = c->d_est[c->cur];   // the estimate this push produced (state already swapped)
     hipStream_t st = c->stream;
     if (c->u8_pushes >= 2) HIPCHK(c, hipStreamWaitEvent(st, c->ev_u8_done[slot], 0));   // frame n-2 has left this slot
     LAUNCHCHK(c, "denorm_u8", launch_denorm_u8(est, c->d_u8[slot], B, 4 * c->h, 4 * c->w * 3, 4 * c->h_in, 4 * c->w_in * 3, st));
     HIPCHK(c, hipEventRecord(c->ev_u8_ready[slot], st));
-    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_u8_ready[slot], 0));
-    // the kernel cropped rows and columns: one dense copy
-    HIPCHK(c, hipMemcpyAsync(est_u8_host, c->d_u8[slot], (size_t)B * 16 * c->h_in * c->w_in * 3, hipMemcpyDeviceToHost, c->copy_stream));
-    HIPCHK(c, hipEventRecord(c->ev_u8_done[slot], c->copy_stream));
+    // its copy to the host: submitted by the next push behind that push's own input copy, or by sr_u8_wait(ctx, 0)
+    c->u8_pending_host = est_u8_host;
+    c->u8_pending_slot = slot;
+    c->u8_pending_bytes = (size_t)B * 16 * c->h_in * c->w_in * 3;
     ++c->u8_pushes;
     return SR_OK;
 }
@@ -1318,10 +1385,12 @@ int sr_u8_wait(sr_ctx* c, int keep_in_flight) {
     if (!c->copy_stream || c->u8_pushes == 0) return SR_OK;
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t n = c->u8_pushes;
-    if (keep_in_flight >= 1) {   // everything but the newest frame
+    if (keep_in_flight >= 1) {   // everything but the newest frame (whose copy the next push submits)
         if (n >= 2) HIPCHK(c, hipEventSynchronize(c->ev_u8_done[(n - 2) & 1]));
         return SR_OK;
     }
+    int rc = u8_flush(c);
+    if (rc) return rc;
     HIPCHK(c, hipEventSynchronize(c->ev_u8_done[(n - 1) & 1]));
     if (n >= 2) HIPCHK(c, hipEventSynchronize(c->ev_u8_done[(n - 2) & 1]));
     return SR_OK;
@@ -1370,8 +1439,12 @@ int sr_clip_read_est_begin(sr_ctx* c, int first, int n, float* est) {
     }
     HIPCHK(c, hipEventRecord(c->ev_est_src, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->est_stream, c->ev_est_src, 0));
-    HIPCHK(c, hipMemcpyAsync(est, src, bytes, hipMemcpyDeviceToHost, c->est_stream));
-    HIPCHK(c, hipEventRecord(c->ev_est_done, c->est_stream));
+    // The copy itself is submitted by the next push, behind that push's input copy (or by sr_clip_read_est_end): the copy
+    // engine serves copies in submission order, and 177 MB of estimates in front of the next frames' 11 MB held that step back
+    // by the whole read-back (3.5 ms on every metric frame of main.py's eval loop).
+    c->est_copy_dst = est;
+    c->est_copy_src = src;
+    c->est_copy_bytes = bytes;
     // the next push reads this estimate, the one after it writes over it; a padded ctx copies from the staging tensor, which
     // no step touches (get_out waits for the copy before it re-uses that tensor)
     c->est_guard = c->pad ? 0 : 2;
@@ -1383,6 +1456,8 @@ int sr_clip_read_est_end(sr_ctx* c) {
     if (!c) return fail(nullptr, SR_ERR_ARG, "ctx is NULL");
     if (!c->est_pending) return fail(c, SR_ERR_STATE, "sr_clip_read_est_end without sr_clip_read_est_begin");
     HIPCHK(c, hipSetDevice(c->device));
+    int rc = est_flush(c);
+    if (rc) return rc;
     HIPCHK(c, hipEventSynchronize(c->ev_est_done));
     c->est_pending = false;
     return SR_OK;

@@ -81,6 +81,17 @@ struct sr_ctx {
     unsigned char* d_u8[2] = {nullptr, nullptr};
     hipEvent_t ev_u8_ready[2] = {nullptr, nullptr}, ev_u8_done[2] = {nullptr, nullptr};
     int64_t u8_pushes = 0;
+    // ... and its HOST inputs: the LR frames of push n go to d_in[n & 1] on `in_stream` when the call is made, i.e. under the
+    // kernels of push n - 1 (on `stream` the copy would wait for them: 0.2 ms per step in the open)
+    float* est_copy_dst = nullptr;       // sr_clip_read_est_begin's copy, not submitted yet (the next push / _end submits it)
+    const float* est_copy_src = nullptr;
+    size_t est_copy_bytes = 0;
+    uint8_t* u8_pending_host = nullptr;  // the newest frame's destination: its D2H is submitted by the next push / sr_u8_wait(ctx, 0)
+    int u8_pending_slot = 0;
+    size_t u8_pending_bytes = 0;
+    hipStream_t in_stream = nullptr;
+    float* d_in[2] = {nullptr, nullptr};
+    hipEvent_t ev_in_ready[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr};
     bool u8_ready = false;   // every object of the path exists (set last; a failed first use frees what it made)
     // float read-back of the newest estimate beside the following step (sr_clip_read_est_begin / _end): its own stream; est_guard
     // counts the pushes that may still start before the copy has to be over (the second one overwrites the buffer it reads)
