@@ -1270,6 +1270,10 @@ int sr_clip_begin(sr_ctx* c, int B) {
     int rc = check_ready(c, B);
     if (rc) return rc;
     const size_t nlr = (size_t)B * c->h * c->w * 3 * 4;
+    if (c->est_pending) {      // a float read-back of the previous clip's last estimates that has not been ended: it reads what the
+        if ((rc = est_flush(c))) return rc;                                  // memsets below clear
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_est_done, 0));
+    }
     // state0 = zeros for prev LR and prev estimate (reference FRVSR.py:233-234)
     HIPCHK(c, hipMemsetAsync(c->d_lr_tm1, 0, nlr, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_est[0], 0, nlr * 16, c->stream));

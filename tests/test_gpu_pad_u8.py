@@ -128,3 +128,50 @@ def test_float_read_back_beside_the_following_steps(sh, weights7, h, w, pad):
         ctx.sync()
         pin.close()
         ctx.close()
+
+
+@pytest.mark.parametrize("finish", ["sync", "clip_begin", "read_end_first"])
+def test_pending_copies_are_submitted_by_whatever_follows(sh, weights7, finish):
+    """The copy-out of the newest uint8 frame (and a float read-back) is only SUBMITTED by the next push, so that the next push's
+    copy-in stands in front of it in the device's copy queue (sr_hip.h).  When no push follows, sr_sync / sr_clip_begin /
+    sr_clip_read_est_end submit it: the last frame of a clip arrives without a sr_u8_wait(ctx, 0), from page-locked and from
+    pageable frames alike."""
+    import utils
+    h, w, B, T = 24, 40, 2, 2
+    clip = np.stack([rn.synth_clip(40 + i, T, h, w) for i in range(B)], axis=1)
+    ctx = sh.Context(h, w, max_batch=B)
+    ctx.load_weights(weights7)
+    ctx.clip_begin(B)
+    want = [ctx.clip_push(clip[t]) for t in range(T)]
+    lr_pin = sh.PinnedArray((T, B, h, w, 3), np.float32)
+    out_pin = sh.PinnedArray((T, B, 4 * h, 4 * w, 3), np.uint8)
+    est_pin = sh.PinnedArray((B, 4 * h, 4 * w, 3), np.float32)
+    try:
+        lr_pin.a[...] = clip
+        out_pin.a[...] = 7
+        est_pin.a[...] = -1.0
+        ctx.clip_begin(B)
+        for t in range(T):
+            ctx.clip_push_u8(lr_pin.ptr + t * lr_pin.a[0].nbytes, out_pin.ptr + t * out_pin.a[0].nbytes)
+        ctx.clip_read_est_begin(est_pin.a, first=0, n=B)      # frame T - 1, nothing follows it
+        if finish == "sync":
+            ctx.sync()
+            np.testing.assert_array_equal(out_pin.a[T - 1], utils.denormalize(want[T - 1]))
+            ctx.clip_read_est_end()
+        elif finish == "clip_begin":
+            ctx.clip_read_est_end()
+            ctx.clip_begin(B)
+            ctx.sync()
+            np.testing.assert_array_equal(out_pin.a[T - 1], utils.denormalize(want[T - 1]))
+        else:
+            ctx.clip_read_est_end()
+            np.testing.assert_array_equal(est_pin.a, want[T - 1])
+            ctx.u8_wait(0)
+            np.testing.assert_array_equal(out_pin.a[T - 1], utils.denormalize(want[T - 1]))
+        np.testing.assert_array_equal(est_pin.a, want[T - 1])
+        np.testing.assert_array_equal(out_pin.a[0], utils.denormalize(want[0]))
+    finally:
+        ctx.sync()
+        for p in (lr_pin, out_pin, est_pin):
+            p.close()
+        ctx.close()
